@@ -1,0 +1,130 @@
+"""ctypes front end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module.  The product (``qldpc_amd``) never does.
+
+The arithmetic lives in ``bp_oracle.c`` (each block cites the reference lines it restates);
+this file only marshals arrays and restates the two integer-only helpers of the reference's
+Monte-Carlo drivers in numpy:
+
+* ``sample_errors_and_syndromes`` = decoding/beliefPropagationGPU.py:181-200
+* ``classify_trials``             = paperResults_GPU.py:113-144 (= paperResults.py:83-100)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+VARIANT_SUM_PRODUCT = 0     # beliefPropagation.py:88-144 / rework/decoding.py:77-129
+VARIANT_DAMPED_SP = 1       # rework/decoding.py:131-191
+VARIANT_MIN_SUM = 2         # rework/decoding.py:5-75
+FLAG_FORCE_FULL = 1
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "bp_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.oracle_bp_decode_batch.restype = C.c_int
+        L.oracle_bp_decode_batch.argtypes = [
+            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+            C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint32,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_mc_errors.restype = None
+        L.oracle_mc_errors.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
+                                       C.c_int64, C.c_void_p]
+        L.oracle_mc_threshold.restype = C.c_uint32
+        L.oracle_mc_threshold.argtypes = [C.c_double]
+        _LIB = L
+    return _LIB
+
+
+def csr_of(H):
+    """(row_ptr, col_idx) int32 with ascending columns per row, from dense or scipy-sparse H."""
+    from scipy.sparse import csr_matrix, issparse
+    S = csr_matrix(H) if issparse(H) else csr_matrix(np.asarray(H, dtype=np.float64))
+    S.sort_indices()
+    S.eliminate_zeros()
+    return (np.ascontiguousarray(S.indptr, dtype=np.int32),
+            np.ascontiguousarray(S.indices, dtype=np.int32), S.shape[0], S.shape[1])
+
+
+def decode_batch(H, syndromes, prior, max_iter=50, variant=0, alpha=1.0, damping=1.0,
+                 clip_llr=20.0, flags=0):
+    """Returns ``(hard u8[B,n], converged bool[B], iters i32[B], llr f64[B,n])``."""
+    row_ptr, col_idx, m, n = csr_of(H)
+    syn = np.ascontiguousarray(np.atleast_2d(np.asarray(syndromes)).astype(np.uint8))
+    B = syn.shape[0]
+    assert syn.shape[1] == m
+    pr = np.ascontiguousarray(np.asarray(prior, dtype=np.float64))
+    assert pr.shape == (n,)
+    hard = np.zeros((B, n), np.uint8)
+    conv = np.zeros(B, np.uint8)
+    iters = np.zeros(B, np.int32)
+    llr = np.zeros((B, n), np.float64)
+    rc = lib().oracle_bp_decode_batch(
+        m, n, row_ptr.ctypes.data, col_idx.ctypes.data, syn.ctypes.data, pr.ctypes.data, B,
+        int(max_iter), int(variant), float(alpha), float(damping), float(clip_llr), int(flags),
+        hard.ctypes.data, conv.ctypes.data, iters.ctypes.data, llr.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"oracle_bp_decode_batch failed: {rc}")
+    return hard, conv.astype(bool), iters, llr
+
+
+def mc_errors(n, p, draws, seed, trial_begin, T):
+    """The build's Philox error sampler (see bp_oracle.c), errors u8[T,n]."""
+    out = np.zeros((T, n), np.uint8)
+    lib().oracle_mc_errors(int(n), float(p), int(draws), int(seed), int(trial_begin), int(T),
+                           out.ctypes.data)
+    return out
+
+
+def sample_errors_and_syndromes(H, error_rate, batch_size, rng):
+    """decoding/beliefPropagationGPU.py:181-200 in numpy (host PCG64 stream)."""
+    H = np.asarray(H)
+    errors = (rng.random((batch_size, H.shape[1])) < error_rate).astype(np.int8)   # :195
+    syndromes = (errors @ H.T) % 2                                                  # :198
+    return errors, syndromes.astype(np.int8)
+
+
+COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
+                 "degenerateErrors", "not_converged", "sum_iterations")
+
+
+def classify_trials(H, Lx, distance, errors, syndromes, detections, converged, iters):
+    """paperResults_GPU.py:113-144 without the OSD call (BP only): int64 counters[8]."""
+    H = np.asarray(H).astype(np.int64)
+    Lx = np.asarray(Lx).astype(np.int64)
+    cnt = np.zeros(8, np.int64)
+    for i in range(errors.shape[0]):
+        error = errors[i].astype(np.int64)
+        detection = detections[i].astype(np.int64)
+        residual = (detection + error) % 2                                   # :127
+        syndrome_logic = (Lx @ residual) % 2                                 # :129
+        is_valid = np.array_equal((detection @ H.T) % 2, syndromes[i])       # :131-132
+        if is_valid and not syndrome_logic.any() and not np.array_equal(detection, error):
+            cnt[5] += 1                                                      # :134-135
+        if syndrome_logic.any():
+            cnt[1] += 1                                                      # :137-138
+            if error.sum() < (distance // 2):                                # :140-141
+                cnt[3] += 1
+            else:
+                cnt[4] += 1
+        cnt[0] += 1
+        cnt[6] += int(not converged[i])
+        cnt[7] += int(iters[i])
+    return cnt
