@@ -1,0 +1,144 @@
+/*
+ * qbp.h -- C ABI of libqbp.so, the MI355X (gfx950) belief-propagation decoder.
+ *
+ * The reference (michelebanfi/qLDPC) has no FFI layer: its operator API for this path is a set
+ * of Python functions.  Each entry point below names the reference function(s) it replaces;
+ * qldpc_amd/bp.py and qldpc_amd/dropin/decoding/ mirror those Python signatures on top of
+ * this ABI through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative QBP_E_* code on failure; the message
+ *     is available from qbp_last_error() (thread-local); no C++ exception crosses the ABI;
+ *   - the caller owns every buffer; "host" entry points take host pointers, copy to and from
+ *     the device on the handle's stream and synchronise before returning; "_device" entry
+ *     points take device pointers, enqueue on the given HIP stream and return immediately;
+ *   - a handle owns the device copies of the code's tables, is bound to one device and is not
+ *     thread-safe (one handle per thread / GPU); distinct handles are independent;
+ *   - there is NO CPU fallback: without a usable HIP device qbp_create fails with
+ *     QBP_E_NO_DEVICE.
+ */
+#ifndef QBP_H
+#define QBP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qbp_handle qbp_handle;
+
+enum {
+    QBP_OK = 0,
+    QBP_E_INVALID = -1,     /* bad argument (shape, range, null pointer)            */
+    QBP_E_NO_DEVICE = -2,   /* no HIP device / device index out of range            */
+    QBP_E_HIP = -3,         /* a HIP runtime call failed                            */
+    QBP_E_UNSUPPORTED = -4, /* matrix too large / too dense for the on-chip kernels */
+    QBP_E_NOMEM = -5
+};
+
+/* message-update rule */
+enum {
+    QBP_SUM_PRODUCT = 0, /* decoding/beliefPropagation.py:88-144 performBeliefPropagationFast
+                            (= :6-85 performBeliefPropagation, rework/decoding.py:77-129,
+                            decoding/beliefPropagationGPU.py:22-78 and :81-178 per sample) */
+    QBP_DAMPED_SP = 1,   /* rework/decoding.py:131-191 performBeliefPropagation_Symmetric   */
+    QBP_MIN_SUM = 2      /* rework/decoding.py:5-75    performMinSum_Symmetric              */
+};
+
+/* flags */
+enum {
+    QBP_FLAG_FORCE_FULL = 1u /* run all max_iter iterations for every syndrome; outputs are still
+                                those of the first converged iteration (bench mode "M2") */
+};
+
+/*
+ * Build a decoder for the parity-check matrix H given in CSR form.
+ *   row_ptr [m+1], col_idx [E] (ascending within each row, no duplicates), m checks, n variables.
+ * Replaces the per-call setup of the reference (csr_matrix(H), mask, adjacency lists:
+ * decoding/beliefPropagation.py:12-23 and :93-101), done once per code instead of per syndrome.
+ */
+int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n,
+               int32_t device, qbp_handle** out);
+void qbp_destroy(qbp_handle* h);
+
+/*
+ * Decode B syndromes (host buffers).
+ *   syndromes [B][m] 0/1 bytes, prior [n] LLRs (initialBelief), max_iter >= 1,
+ *   variant QBP_*, alpha / damping / clip_llr as in rework/decoding.py (ignored by
+ *   QBP_SUM_PRODUCT; alpha is R-scaling for QBP_DAMPED_SP and the normalisation for QBP_MIN_SUM).
+ * Outputs (any may be NULL): hard [B][n] 0/1, converged [B] 0/1, iters [B] (0-based iteration of
+ * the first syndrome match, max_iter-1 if none: rework/decoding.py:127,129), llr [B][n].
+ * Replaces performBeliefPropagationBatch (decoding/beliefPropagationGPU.py:81-178) and, with
+ * B = 1, every single-syndrome entry point listed under the variant enum.
+ */
+int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
+                     int32_t max_iter, int32_t variant, double alpha, double damping,
+                     double clip_llr, uint32_t flags, uint8_t* hard, uint8_t* converged,
+                     int32_t* iters, double* llr);
+
+/* Same, all pointers are DEVICE pointers, enqueued on `stream` (a hipStream_t, may be NULL),
+ * asynchronous.  This is the call bench.py times with inputs resident in HBM. */
+int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior,
+                            int64_t B, int32_t max_iter, int32_t variant, double alpha,
+                            double damping, double clip_llr, uint32_t flags, uint8_t* d_hard,
+                            uint8_t* d_converged, int32_t* d_iters, double* d_llr, void* stream);
+
+/*
+ * Monte-Carlo trials [trial_begin, trial_end) entirely on the device: sample errors, form
+ * syndromes, decode, classify, count.  Replaces the body of the trial loop of
+ * paperResults_GPU.py:89-144 (= paperResults.py:57-100) without its OSD call:
+ *   generate_errors_and_syndromes_batch (decoding/beliefPropagationGPU.py:181-200), `draws` = 2
+ *   reproduces the XOR of two Bernoulli(p) draws (paperResults_GPU.py:96-105);
+ *   performBeliefPropagationBatch; residual / logical check / counters (:113-144).
+ * Errors come from Philox4x32-10 keyed by (seed, global trial index, qubit): the union of trials
+ * is identical however the range is split over GPUs (oracle/bp_oracle.c states the sampler).
+ *   Lx [k][n] 0/1 bytes (k <= 64), distance as in codes/<name>.npz, prior [n] (the decoder's
+ *   prior is an input, as in the reference, and need not match p).
+ * counters[QBP_NUM_COUNTERS] (int64, ADDED to):
+ *   [0] trials  [1] logical_error  [2] BPs_fault (always 0, as in the reference)
+ *   [3] BPs_miscorrected  [4] incorrectable  [5] degenerateErrors          (:80-84, :133-144)
+ *   [6] not_converged (= trials the reference would hand to OSD)  [7] sum of iteration indices
+ *   [8] logical_error among not_converged  [9] hard == error exactly  [10], [11] reserved (0).
+ */
+#define QBP_NUM_COUNTERS 12
+int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, double p,
+               int32_t draws, uint64_t seed, int64_t trial_begin, int64_t trial_end,
+               const double* prior, int32_t max_iter, int32_t variant, double alpha,
+               double damping, double clip_llr, uint32_t flags, int64_t counters[QBP_NUM_COUNTERS]);
+
+/* Asynchronous form: d_prior and d_counters (int64[QBP_NUM_COUNTERS], ADDED to) are device
+ * pointers; Lx stays a host pointer (uploaded once per handle and cached). */
+int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t distance,
+                      double p, int32_t draws, uint64_t seed, int64_t trial_begin,
+                      int64_t trial_end, const double* d_prior, int32_t max_iter,
+                      int32_t variant, double alpha, double damping, double clip_llr,
+                      uint32_t flags, int64_t* d_counters, void* stream);
+
+/* Errors the sampler of qbp_mc_run draws for trials [trial_begin, trial_begin + T):
+ * errors [T][n] host bytes.  For tests (compared bit for bit with the oracle's restatement). */
+int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
+                         int64_t trial_begin, int64_t T, uint8_t* errors);
+
+/* Tuning / introspection. */
+enum {
+    QBP_OPT_SLOTS_PER_BLOCK = 1, /* syndromes decoded concurrently by one workgroup (0 = auto) */
+    QBP_OPT_BLOCKS_PER_CU = 2,   /* persistent workgroups per CU (0 = auto)                    */
+    QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
+    QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 fused on-chip, 2 generic */
+    QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109
+};
+int qbp_set_option(qbp_handle* h, int32_t option, int64_t value);
+int64_t qbp_get_info(qbp_handle* h, int32_t what);
+
+/* Device evaluation of the kernels' FP64 elementary functions, for accuracy tests:
+ * kind 0: tanh(x/2), kind 1: 2*atanh(x).  Host buffers. */
+int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int64_t count);
+
+const char* qbp_last_error(void);
+const char* qbp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QBP_H */

@@ -1,0 +1,172 @@
+"""ctypes binding of ``libqbp.so`` (C ABI: ``include/qbp.h``).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible, every
+entry point raises (``QbpError``) instead of computing something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqbp.so")
+
+SUM_PRODUCT, DAMPED_SP, MIN_SUM = 0, 1, 2
+FLAG_FORCE_FULL = 1
+NUM_COUNTERS = 12
+COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
+                 "degenerateErrors", "not_converged", "sum_iterations",
+                 "logical_error_not_converged", "exact_recoveries", "reserved0", "reserved1")
+OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU = 1, 2
+INFO = dict(m=100, n=101, edges=102, max_row_deg=103, max_col_deg=104, kernel_kind=105,
+            threads=106, lds_bytes=107, grid=108, num_cu=109)
+
+# every symbol include/qbp.h declares: (restype, argtypes)
+_VP = C.c_void_p
+SIGNATURES = {
+    "qbp_create": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "qbp_destroy": (None, [_VP]),
+    "qbp_decode_batch": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_double,
+                                   C.c_double, C.c_double, C.c_uint32, _VP, _VP, _VP, _VP]),
+    "qbp_decode_batch_device": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_double, C.c_double, C.c_double, C.c_uint32, _VP,
+                                          _VP, _VP, _VP, _VP]),
+    "qbp_mc_run": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_uint64,
+                             C.c_int64, C.c_int64, _VP, C.c_int32, C.c_int32, C.c_double,
+                             C.c_double, C.c_double, C.c_uint32, _VP]),
+    "qbp_mc_run_device": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                    C.c_uint64, C.c_int64, C.c_int64, _VP, C.c_int32, C.c_int32,
+                                    C.c_double, C.c_double, C.c_double, C.c_uint32, _VP, _VP]),
+    "qbp_mc_sample_errors": (C.c_int, [_VP, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
+                                       C.c_int64, _VP]),
+    "qbp_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
+    "qbp_get_info": (C.c_int64, [_VP, C.c_int32]),
+    "qbp_debug_math": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int64]),
+    "qbp_last_error": (C.c_char_p, []),
+    "qbp_version": (C.c_char_p, []),
+}
+
+
+class QbpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libqbp.so (built by ``__graft_entry__.build()`` / ``make -C qldpc_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QbpError(f"{LIB_PATH} is missing: build it with `python -c 'import "
+                           f"__graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise QbpError(f"libqbp error {rc}: {load().qbp_last_error().decode()}")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Decoder:
+    """One parity-check matrix on one GPU (wraps a ``qbp_handle``)."""
+
+    def __init__(self, row_ptr, col_idx, m, n, device=0):
+        lib = load()
+        self.row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        self.col_idx = np.ascontiguousarray(col_idx, np.int32)
+        self.m, self.n = int(m), int(n)
+        h = _VP()
+        _check(lib.qbp_create(self.row_ptr.ctypes.data, _ptr(self.col_idx), self.m, self.n,
+                              int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().qbp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def info(self, what):
+        return int(load().qbp_get_info(self._h, INFO[what]))
+
+    def set_option(self, option, value):
+        _check(load().qbp_set_option(self._h, int(option), int(value)))
+
+    # ---- host buffers ----------------------------------------------------------------------
+    def decode(self, syndromes, prior, max_iter=50, variant=SUM_PRODUCT, alpha=1.0, damping=1.0,
+               clip_llr=20.0, flags=0, want_llr=True):
+        syn = np.ascontiguousarray(syndromes, np.uint8)
+        if syn.ndim != 2 or syn.shape[1] != self.m:
+            raise ValueError(f"syndromes must have shape (B, {self.m}), got {syn.shape}")
+        pr = np.ascontiguousarray(prior, np.float64)
+        if pr.shape != (self.n,):
+            raise ValueError(f"initialBelief must have shape ({self.n},), got {pr.shape}")
+        B = syn.shape[0]
+        hard = np.empty((B, self.n), np.uint8)
+        conv = np.empty(B, np.uint8)
+        iters = np.empty(B, np.int32)
+        llr = np.empty((B, self.n), np.float64) if want_llr else None
+        _check(load().qbp_decode_batch(self._h, syn.ctypes.data, pr.ctypes.data, B, int(max_iter),
+                                       int(variant), float(alpha), float(damping),
+                                       float(clip_llr), int(flags), hard.ctypes.data,
+                                       conv.ctypes.data, iters.ctypes.data, _ptr(llr)))
+        return hard, conv.astype(bool), iters, llr
+
+    # ---- device buffers (raw pointers, e.g. torch tensors' data_ptr()) ----------------------
+    def decode_device(self, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr,
+                      flags, d_hard, d_converged, d_iters, d_llr, stream=0):
+        _check(load().qbp_decode_batch_device(
+            self._h, d_syndromes, d_prior, int(B), int(max_iter), int(variant), float(alpha),
+            float(damping), float(clip_llr), int(flags), d_hard or None, d_converged or None,
+            d_iters or None, d_llr or None, stream or None))
+
+    def mc_run(self, Lx, distance, p, prior, trial_begin, trial_end, draws=1, seed=0, max_iter=50,
+               variant=SUM_PRODUCT, alpha=1.0, damping=1.0, clip_llr=20.0, flags=0):
+        Lx = np.ascontiguousarray(Lx, np.uint8)
+        pr = np.ascontiguousarray(prior, np.float64)
+        if Lx.ndim != 2 or Lx.shape[1] != self.n:
+            raise ValueError(f"Lx must have shape (k, {self.n})")
+        if pr.shape != (self.n,):
+            raise ValueError(f"prior must have shape ({self.n},)")
+        counters = np.zeros(NUM_COUNTERS, np.int64)
+        _check(load().qbp_mc_run(self._h, Lx.ctypes.data, Lx.shape[0], int(distance), float(p),
+                                 int(draws), int(seed), int(trial_begin), int(trial_end),
+                                 pr.ctypes.data, int(max_iter), int(variant), float(alpha),
+                                 float(damping), float(clip_llr), int(flags), counters.ctypes.data))
+        return counters
+
+    def mc_run_device(self, Lx, distance, p, d_prior, trial_begin, trial_end, d_counters, draws=1,
+                      seed=0, max_iter=50, variant=SUM_PRODUCT, alpha=1.0, damping=1.0,
+                      clip_llr=20.0, flags=0, stream=0):
+        Lx = np.ascontiguousarray(Lx, np.uint8)
+        _check(load().qbp_mc_run_device(
+            self._h, Lx.ctypes.data, Lx.shape[0], int(distance), float(p), int(draws), int(seed),
+            int(trial_begin), int(trial_end), d_prior, int(max_iter), int(variant), float(alpha),
+            float(damping), float(clip_llr), int(flags), d_counters, stream or None))
+
+    def mc_sample_errors(self, p, trial_begin, T, draws=1, seed=0):
+        out = np.empty((int(T), self.n), np.uint8)
+        _check(load().qbp_mc_sample_errors(self._h, float(p), int(draws), int(seed),
+                                           int(trial_begin), int(T), out.ctypes.data))
+        return out
+
+    def debug_math(self, kind, x):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.empty_like(x)
+        _check(load().qbp_debug_math(self._h, int(kind), x.ctypes.data, y.ctypes.data, x.size))
+        return y

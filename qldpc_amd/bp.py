@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's BP operator API, backed by ``libqbp.so`` (HIP, gfx950).
+
+Same names, positional order, defaults, return arity, dtypes and printed lines as
+
+* ``decoding/beliefPropagation.py``     performBeliefPropagation (:6), performBeliefPropagationFast (:88)
+* ``decoding/beliefPropagationGPU.py``  performBeliefPropagationGPU (:22), performBeliefPropagationBatch (:81),
+                                        generate_errors_and_syndromes_batch (:181), GPU_AVAILABLE
+* ``rework/decoding.py``                see ``qldpc_amd/rework.py`` (4-tuple variants)
+
+All decoding runs on the MI355X; there is no CPU path in this package.  Deviations from the
+reference, all on inputs the reference does not handle either:
+``maxIter < 1`` raises ``ValueError`` (reference: ``UnboundLocalError``), shape mismatches raise
+``ValueError`` (reference: numpy ``IndexError``/broadcast errors), syndrome entries must be 0/1.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from . import _lib
+
+try:  # fast content hash for the per-call decoder cache
+    import xxhash
+
+    def _digest(buf) -> bytes:
+        return xxhash.xxh3_128_digest(buf)
+except Exception:  # pragma: no cover
+    def _digest(buf) -> bytes:
+        return hashlib.blake2b(buf, digest_size=16).digest()
+
+_DECODERS: dict = {}
+_MAX_CACHED = 16
+DEVICE = 0          # HIP device used by the module-level functions (one process per GPU)
+
+
+def csr_from_H(H):
+    """CSR (row_ptr, col_idx, m, n) of the non-zeros of H, columns ascending -- the order in
+    which the reference multiplies / sums (np.prod(axis=1), csr indices: beliefPropagation.py:22)."""
+    try:
+        from scipy.sparse import issparse
+    except Exception:  # pragma: no cover
+        def issparse(_):
+            return False
+    if issparse(H):
+        S = H.tocsr().copy()
+        S.sum_duplicates()
+        S.eliminate_zeros()
+        S.sort_indices()
+        return (np.ascontiguousarray(S.indptr, np.int32), np.ascontiguousarray(S.indices, np.int32),
+                int(S.shape[0]), int(S.shape[1]))
+    A = np.asarray(H)
+    if A.ndim != 2:
+        raise ValueError(f"H must be 2-D, got shape {A.shape}")
+    rows, cols = np.nonzero(A)             # row-major order: ascending columns within a row
+    row_ptr = np.zeros(A.shape[0] + 1, np.int32)
+    np.cumsum(np.bincount(rows, minlength=A.shape[0]), out=row_ptr[1:])
+    return row_ptr, np.ascontiguousarray(cols, np.int32), int(A.shape[0]), int(A.shape[1])
+
+
+def decoder_for(H, device=None) -> _lib.Decoder:
+    """Decoder handle for H, cached on the matrix content (the reference re-derives the graph on
+    every call; here that happens once per code)."""
+    device = DEVICE if device is None else device
+    try:
+        from scipy.sparse import issparse
+        sparse = issparse(H)
+    except Exception:  # pragma: no cover
+        sparse = False
+    if sparse:
+        S = H.tocsr()
+        key = ("s", S.shape, _digest(np.ascontiguousarray(S.indptr)),
+               _digest(np.ascontiguousarray(S.indices)), _digest(np.ascontiguousarray(S.data)),
+               device)
+    else:
+        A = np.ascontiguousarray(H)
+        key = ("d", A.shape, A.dtype.str, _digest(A), device)
+    dec = _DECODERS.get(key)
+    if dec is None:
+        row_ptr, col_idx, m, n = csr_from_H(H)
+        dec = _lib.Decoder(row_ptr, col_idx, m, n, device)
+        if len(_DECODERS) >= _MAX_CACHED:
+            _DECODERS.pop(next(iter(_DECODERS))).close()
+        _DECODERS[key] = dec
+    return dec
+
+
+def _syndromes(s, m, batch):
+    a = np.asarray(s)
+    if a.dtype == bool:
+        a = a.astype(np.int8)
+    a = np.asarray(a, dtype=np.int8)            # as the reference casts (:94)
+    want = 2 if batch else 1
+    if a.ndim != want or a.shape[-1] != m:
+        raise ValueError(f"syndrome has shape {a.shape}, expected {'(B, ' if batch else '('}{m})")
+    if ((a != 0) & (a != 1)).any():
+        raise ValueError("syndrome entries must be 0 or 1")
+    return a
+
+
+def _prior(initialBelief, n):
+    p = np.asarray(initialBelief, dtype=np.float64)
+    if p.shape != (n,):
+        raise ValueError(f"initialBelief has shape {p.shape}, expected ({n},)")
+    return p
+
+
+def _check_iter(maxIter):
+    if int(maxIter) < 1:
+        raise ValueError(f"maxIter must be >= 1, got {maxIter}")
+    return int(maxIter)
+
+
+def decode_one(H, syndrome, initialBelief, maxIter, variant=_lib.SUM_PRODUCT, alpha=1.0,
+               damping=1.0, clip_llr=20.0):
+    """(hard int8[n], converged bool, llr float64[n], iteration int) for one syndrome."""
+    dec = decoder_for(H)
+    syn = _syndromes(syndrome, dec.m, batch=False)
+    hard, conv, iters, llr = dec.decode(syn[None, :].astype(np.uint8), _prior(initialBelief, dec.n),
+                                        _check_iter(maxIter), variant, alpha, damping, clip_llr)
+    return hard[0].astype(np.int8), bool(conv[0]), llr[0], int(iters[0])
+
+
+def performBeliefPropagationFast(H, syndrome, initialBelief, verbose=True, maxIter=50):
+    """decoding/beliefPropagation.py:88-144."""
+    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter)
+    if conv and verbose:
+        print(f"Error found at iteration {it}: {hard}")                      # :141
+    return hard, conv, llr
+
+
+def performBeliefPropagation(H, syndrome, initialBelief, verbose=True, plotPath=None, maxIter=50):
+    """decoding/beliefPropagation.py:6-85 (accepts scipy-sparse H, :8-10)."""
+    if verbose:
+        print(f"Initial syndrome: {np.asarray(syndrome, dtype=np.int8)}")    # :28
+    if plotPath is not None:                                                 # :30-31
+        from drawUtils import plotGraph   # the reference's plotting helper, if importable
+        try:
+            from scipy.sparse import issparse
+            dense = H.toarray() if issparse(H) else np.asarray(H, dtype=np.float64)
+        except Exception:  # pragma: no cover
+            dense = np.asarray(H, dtype=np.float64)
+        plotGraph(dense, path=plotPath)
+    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter)
+    if conv and verbose:
+        print(f"Error found at iteration {it}: {hard}")                      # :82
+    return hard, conv, llr
+
+
+def performBeliefPropagationGPU(H, syndrome, initialBelief, verbose=False, maxIter=50):
+    """decoding/beliefPropagationGPU.py:22-78."""
+    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter)
+    if conv and verbose:
+        print(f"Error found at iteration {it}")                              # :73
+    return hard, conv, llr
+
+
+def performBeliefPropagationBatch(H, syndromes, initialBelief, maxIter=50):
+    """decoding/beliefPropagationGPU.py:81-178 -> (int8[B, n], bool[B], float64[B, n])."""
+    dec = decoder_for(H)
+    syn = _syndromes(syndromes, dec.m, batch=True)
+    hard, conv, _, llr = dec.decode(syn.astype(np.uint8), _prior(initialBelief, dec.n),
+                                    _check_iter(maxIter))
+    return hard.astype(np.int8), conv, llr
+
+
+def generate_errors_and_syndromes_batch(H, error_rate, batch_size, rng=None):
+    """decoding/beliefPropagationGPU.py:181-200.  Host numpy on purpose: callers pass a numpy
+    Generator (paperResults_GPU.py:34) and rely on its stream; the device Monte-Carlo path
+    (qldpc_amd.mc) has its own counter-based sampler."""
+    if rng is None:
+        rng = np.random.default_rng()
+    H = np.asarray(H)
+    num_vars = H.shape[1]
+    errors = (rng.random((batch_size, num_vars)) < error_rate).astype(np.int8)
+    syndromes = (errors @ H.T) % 2
+    return errors, syndromes.astype(np.int8)
+
+
+def gpu_available() -> bool:
+    """True when libqbp.so loads and sees a device (the shim's GPU_AVAILABLE)."""
+    try:
+        import ctypes as C
+        lib = _lib.load()
+        h = C.c_void_p()
+        rp = np.array([0, 1], np.int32)
+        ci = np.array([0], np.int32)
+        rc = lib.qbp_create(rp.ctypes.data, ci.ctypes.data, 1, 1, DEVICE, C.byref(h))
+        if rc == 0:
+            lib.qbp_destroy(h)
+        return rc == 0
+    except Exception:
+        return False

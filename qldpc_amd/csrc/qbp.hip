@@ -1,0 +1,525 @@
+// libqbp.so -- host side of the C ABI declared in include/qbp.h (gfx950 only, no CPU fallback).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/qbp.h"
+#include "qbp_kernels.hpp"
+
+static_assert(QBP_NUM_COUNTERS == qbp::NUM_COUNTERS, "counter layout");
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(QBP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+constexpr int DC_FUSED = 6;   // widest row / column the instantiated on-chip kernel handles
+constexpr int DV_FUSED = 3;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t count)
+    {
+        if (count <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) cap = count;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct qbp_handle {
+    int device = 0;
+    int m = 0, n = 0, E = 0;
+    int max_row_deg = 0, max_col_deg = 0;
+    int num_cu = 0;
+    bool fused_ok = false;
+    bool padded = false;
+    std::vector<int32_t> row_ptr, col_idx;
+    // device tables for the fused kernel
+    DevBuf<int32_t> d_tab_var;
+    DevBuf<uint16_t> d_tab_nbr;
+    DevBuf<uint32_t> d_tab_writer;
+    DevBuf<int32_t> d_iso;
+    int n_iso = 0;
+    DevBuf<unsigned long long> d_work_counter;
+    // options
+    int opt_slots = 0, opt_blocks_per_cu = 0;
+    // last launch configuration (introspection)
+    int last_threads = 0, last_lds = 0, last_grid = 0;
+    // scratch for the host-pointer entry points
+    hipStream_t stream = nullptr;
+    DevBuf<uint8_t> d_syn, d_hard, d_conv, d_lx_bytes;
+    DevBuf<int32_t> d_iters;
+    DevBuf<double> d_llr, d_prior, d_mathx, d_mathy;
+    DevBuf<unsigned long long> d_lx_cols;
+    DevBuf<long long> d_counters;
+    std::vector<uint8_t> lx_cache;   // last uploaded Lx (host copy) to skip re-uploads
+    int lx_cache_k = -1;
+};
+
+namespace {
+
+using qbp::FusedParams;
+
+struct LaunchCfg {
+    int S, threads, lds_bytes, grid, slot_stride;
+};
+
+template <int VARIANT, bool MC, int MAXT>
+hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
+{
+    auto kern = qbp::bp_fused_kernel<DC_FUSED, DV_FUSED, VARIANT, MC, MAXT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(cfg.threads), cfg.lds_bytes, stream, P);
+    return hipGetLastError();
+}
+
+template <bool MC>
+hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s)
+{
+    const bool small = cfg.threads <= 640;
+    switch (variant) {
+        case QBP_SUM_PRODUCT:
+            return small ? launch_one<0, MC, 640>(P, cfg, s) : launch_one<0, MC, 1024>(P, cfg, s);
+        case QBP_DAMPED_SP:
+            return small ? launch_one<1, MC, 640>(P, cfg, s) : launch_one<1, MC, 1024>(P, cfg, s);
+        default:
+            return small ? launch_one<2, MC, 640>(P, cfg, s) : launch_one<2, MC, 1024>(P, cfg, s);
+    }
+}
+
+int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
+{
+    const int m = h->m;
+    int S = h->opt_slots;
+    if (S <= 0) S = std::max(1, 576 / std::max(m, 1));      // 576 = 9 wavefronts
+    S = std::min(S, std::max(1, 1024 / std::max(m, 1)));
+    if ((long long)S > B) S = (int)std::max<long long>(B, 1);
+    cfg->S = S;
+    cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
+    cfg->slot_stride = DC_FUSED * m + 2;
+    size_t lds = ((size_t)S * cfg->slot_stride + 2 * (size_t)S) * 8 + (4 * (size_t)S + 1) * 4;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
+    cfg->lds_bytes = (int)lds;
+    int per_cu = h->opt_blocks_per_cu;
+    if (per_cu <= 0) {
+        // resident workgroups per CU: limited by wavefront slots (32 per CU; the kernel's VGPR
+        // budget admits <= 3-4 waves per SIMD) and by LDS
+        const int waves = cfg->threads / 64;
+        per_cu = std::max(1, std::min(12 / std::max(waves, 1), (int)(160 * 1024 / lds)));
+        if (waves > 12) per_cu = 1;
+    }
+    const long long want = (B + S - 1) / S;
+    cfg->grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cu * per_cu));
+    h->last_threads = cfg->threads;
+    h->last_lds = cfg->lds_bytes;
+    h->last_grid = cfg->grid;
+    return QBP_OK;
+}
+
+int check_decode_args(qbp_handle* h, long long B, int max_iter, int variant)
+{
+    if (!h) return fail(QBP_E_INVALID, "null handle");
+    if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0 (got %lld)", B);
+    if (max_iter < 1)
+        return fail(QBP_E_INVALID, "max_iter must be >= 1 (got %d); the reference raises "
+                                   "UnboundLocalError for maxIter=0", max_iter);
+    if (variant < 0 || variant > 2) return fail(QBP_E_INVALID, "unknown variant %d", variant);
+    if (!h->fused_ok)
+        return fail(QBP_E_UNSUPPORTED,
+                    "H (m=%d, max row degree %d, max column degree %d) does not fit the on-chip "
+                    "kernel (m <= 1024, row degree <= %d, column degree <= %d)",
+                    h->m, h->max_row_deg, h->max_col_deg, DC_FUSED, DV_FUSED);
+    return QBP_OK;
+}
+
+void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg)
+{
+    P.m = h->m; P.n = h->n;
+    P.S = cfg.S; P.slot_stride = cfg.slot_stride;
+    P.padded = h->padded ? 1 : 0;
+    P.tab_var = h->d_tab_var.p; P.tab_nbr = h->d_tab_nbr.p; P.tab_writer = h->d_tab_writer.p;
+    P.iso_vars = h->d_iso.p; P.n_iso = h->n_iso;
+    P.work_counter = h->d_work_counter.p;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* qbp_last_error(void) { return g_err; }
+const char* qbp_version(void) { return "qbp 0.1 (gfx950)"; }
+
+int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n,
+               int32_t device, qbp_handle** out)
+{
+    if (!out) return fail(QBP_E_INVALID, "out is null");
+    *out = nullptr;
+    if (!row_ptr || m < 0 || n < 0) return fail(QBP_E_INVALID, "bad matrix arguments");
+    if (m == 0 || n == 0) return fail(QBP_E_INVALID, "empty matrix (%d x %d)", m, n);
+    if (row_ptr[0] != 0) return fail(QBP_E_INVALID, "row_ptr[0] must be 0");
+    const int E = row_ptr[m];
+    if (E < 0 || (E > 0 && !col_idx)) return fail(QBP_E_INVALID, "bad CSR arrays");
+    std::vector<int> col_deg(n, 0);
+    int max_row = 0;
+    for (int c = 0; c < m; ++c) {
+        if (row_ptr[c + 1] < row_ptr[c]) return fail(QBP_E_INVALID, "row_ptr not monotone at %d", c);
+        max_row = std::max(max_row, row_ptr[c + 1] - row_ptr[c]);
+        for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e) {
+            if (col_idx[e] < 0 || col_idx[e] >= n)
+                return fail(QBP_E_INVALID, "column index %d out of range in row %d", col_idx[e], c);
+            if (e > row_ptr[c] && col_idx[e] <= col_idx[e - 1])
+                return fail(QBP_E_INVALID, "columns of row %d not strictly ascending", c);
+            col_deg[col_idx[e]]++;
+        }
+    }
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev <= 0)
+        return fail(QBP_E_NO_DEVICE, "no HIP device available (%s); libqbp has no CPU fallback",
+                    de == hipSuccess ? "device count 0" : hipGetErrorString(de));
+    if (device < 0 || device >= ndev)
+        return fail(QBP_E_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    qbp_handle* h = new (std::nothrow) qbp_handle();
+    if (!h) return fail(QBP_E_NOMEM, "out of host memory");
+    h->device = device; h->m = m; h->n = n; h->E = E;
+    h->row_ptr.assign(row_ptr, row_ptr + m + 1);
+    h->col_idx.assign(col_idx, col_idx + E);
+    h->max_row_deg = max_row;
+    h->max_col_deg = *std::max_element(col_deg.begin(), col_deg.end());
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QBP_E_HIP, "hipGetDeviceProperties failed"); }
+    h->num_cu = prop.multiProcessorCount;
+    h->fused_ok = (m <= 1024) && max_row <= DC_FUSED && h->max_col_deg <= DV_FUSED &&
+                  ((size_t)(DC_FUSED * m + 2) * 8 + 64 <= 160 * 1024);
+
+    // ---- tables of the fused kernel -------------------------------------------------------
+    // column lists in ascending check order: (check, position in that check's row)
+    std::vector<std::vector<std::pair<int, int>>> cols(n);
+    for (int c = 0; c < m; ++c)
+        for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e)
+            cols[col_idx[e]].push_back({c, e - row_ptr[c]});
+    std::vector<int32_t> iso;
+    for (int v = 0; v < n; ++v) if (cols[v].empty()) iso.push_back(v);
+    h->n_iso = (int)iso.size();
+    hipError_t e1 = hipSuccess;
+    auto up = [&](auto& buf, const auto& vec) {
+        if (e1 != hipSuccess) return;
+        e1 = buf.reserve(vec.size());
+        if (e1 == hipSuccess && !vec.empty())
+            e1 = hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice);
+    };
+    if (h->fused_ok) {
+        const int DC = DC_FUSED, DV = DV_FUSED;
+        const int zoff = DC * m;
+        std::vector<int32_t> tab_var((size_t)DC * m, -1);
+        std::vector<uint16_t> tab_nbr((size_t)DC * DV * m, (uint16_t)zoff);
+        std::vector<uint32_t> tab_writer(m, 0u);
+        for (int c = 0; c < m; ++c) {
+            const int deg = row_ptr[c + 1] - row_ptr[c];
+            if (deg < DC) h->padded = true;
+            for (int j = 0; j < deg; ++j) {
+                const int v = col_idx[row_ptr[c] + j];
+                tab_var[(size_t)j * m + c] = v;
+                const auto& col = cols[v];
+                for (size_t k = 0; k < col.size(); ++k)
+                    tab_nbr[((size_t)j * DV + k) * m + c] = (uint16_t)(col[k].second * m + col[k].first);
+                if (col[0].first == c) tab_writer[c] |= 1u << j;
+            }
+        }
+        up(h->d_tab_var, tab_var);
+        up(h->d_tab_nbr, tab_nbr);
+        up(h->d_tab_writer, tab_writer);
+    }
+    up(h->d_iso, iso);
+    if (e1 == hipSuccess) e1 = h->d_work_counter.reserve(1);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e1 != hipSuccess) {
+        int rc = fail(QBP_E_HIP, "device setup failed: %s", hipGetErrorString(e1));
+        qbp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return QBP_OK;
+}
+
+void qbp_destroy(qbp_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    h->d_tab_var.release(); h->d_tab_nbr.release(); h->d_tab_writer.release(); h->d_iso.release();
+    h->d_work_counter.release(); h->d_syn.release(); h->d_hard.release(); h->d_conv.release();
+    h->d_lx_bytes.release(); h->d_iters.release(); h->d_llr.release(); h->d_prior.release();
+    h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
+    delete h;
+}
+
+int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior,
+                            int64_t B, int32_t max_iter, int32_t variant, double alpha,
+                            double damping, double clip_llr, uint32_t flags, uint8_t* d_hard,
+                            uint8_t* d_converged, int32_t* d_iters, double* d_llr, void* stream)
+{
+    int rc = check_decode_args(h, B, max_iter, variant);
+    if (rc) return rc;
+    if (B == 0) return QBP_OK;
+    if (!d_syndromes || !d_prior) return fail(QBP_E_INVALID, "null input pointer");
+    if (B > (int64_t)1 << 40) return fail(QBP_E_INVALID, "B too large");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LaunchCfg cfg;
+    rc = make_cfg(h, B, &cfg);
+    if (rc) return rc;
+    FusedParams P{};
+    fill_static(h, P, cfg);
+    P.syndromes = d_syndromes; P.prior = d_prior; P.B = B;
+    P.max_iter = max_iter; P.flags = flags;
+    P.alpha = alpha; P.damping = damping; P.clip_llr = clip_llr;
+    P.hard = d_hard; P.converged = d_converged; P.iters = d_iters; P.llr = d_llr;
+    HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
+    HIP_TRY(launch_variant<false>(variant, P, cfg, s));
+    return QBP_OK;
+}
+
+int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
+                     int32_t max_iter, int32_t variant, double alpha, double damping,
+                     double clip_llr, uint32_t flags, uint8_t* hard, uint8_t* converged,
+                     int32_t* iters, double* llr)
+{
+    int rc = check_decode_args(h, B, max_iter, variant);
+    if (rc) return rc;
+    if (B == 0) return QBP_OK;
+    if (!syndromes || !prior) return fail(QBP_E_INVALID, "null input pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t m = h->m, n = h->n, b = (size_t)B;
+    HIP_TRY(h->d_syn.reserve(b * m));
+    HIP_TRY(h->d_prior.reserve(n));
+    if (hard) HIP_TRY(h->d_hard.reserve(b * n));
+    if (converged) HIP_TRY(h->d_conv.reserve(b));
+    if (iters) HIP_TRY(h->d_iters.reserve(b));
+    if (llr) HIP_TRY(h->d_llr.reserve(b * n));
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->d_syn.p, syndromes, b * m, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior, n * sizeof(double), hipMemcpyHostToDevice, s));
+    rc = qbp_decode_batch_device(h, h->d_syn.p, h->d_prior.p, B, max_iter, variant, alpha, damping,
+                                 clip_llr, flags, hard ? h->d_hard.p : nullptr,
+                                 converged ? h->d_conv.p : nullptr, iters ? h->d_iters.p : nullptr,
+                                 llr ? h->d_llr.p : nullptr, s);
+    if (rc) return rc;
+    if (hard) HIP_TRY(hipMemcpyAsync(hard, h->d_hard.p, b * n, hipMemcpyDeviceToHost, s));
+    if (converged) HIP_TRY(hipMemcpyAsync(converged, h->d_conv.p, b, hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters.p, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (llr) HIP_TRY(hipMemcpyAsync(llr, h->d_llr.p, b * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return QBP_OK;
+}
+
+static int mc_prepare(qbp_handle* h, const uint8_t* Lx, int32_t k, hipStream_t s)
+{
+    if (k < 0 || k > 64) return fail(QBP_E_INVALID, "k = %d logical operators (need 0..64)", k);
+    if (k > 0 && !Lx) return fail(QBP_E_INVALID, "Lx is null");
+    const size_t n = h->n;
+    if (h->lx_cache_k == k && h->lx_cache.size() == (size_t)k * n &&
+        (k == 0 || std::memcmp(h->lx_cache.data(), Lx, (size_t)k * n) == 0))
+        return QBP_OK;
+    std::vector<unsigned long long> cols(n, 0ull);
+    for (int l = 0; l < k; ++l)
+        for (size_t v = 0; v < n; ++v)
+            if (Lx[(size_t)l * n + v] & 1) cols[v] |= 1ull << l;
+    HIP_TRY(h->d_lx_cols.reserve(n));
+    HIP_TRY(hipMemcpyAsync(h->d_lx_cols.p, cols.data(), n * sizeof(unsigned long long),
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // cols is a local
+    h->lx_cache.assign(Lx, Lx + (size_t)k * n);
+    h->lx_cache_k = k;
+    return QBP_OK;
+}
+
+static unsigned mc_threshold(double p)
+{
+    double t = std::floor(p * 4294967296.0);
+    if (!(t > 0.0)) t = 0.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (unsigned)t;
+}
+
+int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t distance,
+                      double p, int32_t draws, uint64_t seed, int64_t trial_begin,
+                      int64_t trial_end, const double* d_prior, int32_t max_iter,
+                      int32_t variant, double alpha, double damping, double clip_llr,
+                      uint32_t flags, int64_t* d_counters, void* stream)
+{
+    const int64_t T = trial_end - trial_begin;
+    int rc = check_decode_args(h, T, max_iter, variant);
+    if (rc) return rc;
+    if (trial_begin < 0) return fail(QBP_E_INVALID, "trial_begin must be >= 0");
+    if (draws != 1 && draws != 2) return fail(QBP_E_INVALID, "draws must be 1 or 2 (got %d)", draws);
+    if (!(p >= 0.0 && p <= 1.0)) return fail(QBP_E_INVALID, "p = %g out of [0, 1]", p);
+    if (!d_prior || !d_counters) return fail(QBP_E_INVALID, "null pointer");
+    if (T == 0) return QBP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = mc_prepare(h, Lx_host, k, s);
+    if (rc) return rc;
+    LaunchCfg cfg;
+    rc = make_cfg(h, T, &cfg);
+    if (rc) return rc;
+    FusedParams P{};
+    fill_static(h, P, cfg);
+    P.prior = d_prior; P.B = T; P.max_iter = max_iter; P.flags = flags;
+    P.alpha = alpha; P.damping = damping; P.clip_llr = clip_llr;
+    P.lx_cols = h->d_lx_cols.p; P.trial_begin = trial_begin; P.seed = seed;
+    P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = distance / 2;
+    P.counters = reinterpret_cast<long long*>(d_counters);
+    HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
+    HIP_TRY(launch_variant<true>(variant, P, cfg, s));
+    return QBP_OK;
+}
+
+int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, double p,
+               int32_t draws, uint64_t seed, int64_t trial_begin, int64_t trial_end,
+               const double* prior, int32_t max_iter, int32_t variant, double alpha,
+               double damping, double clip_llr, uint32_t flags, int64_t counters[QBP_NUM_COUNTERS])
+{
+    if (!h) return fail(QBP_E_INVALID, "null handle");
+    if (!prior || !counters) return fail(QBP_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    HIP_TRY(h->d_prior.reserve(h->n));
+    HIP_TRY(h->d_counters.reserve(qbp::NUM_COUNTERS));
+    HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior, h->n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, qbp::NUM_COUNTERS * sizeof(long long), s));
+    int rc = qbp_mc_run_device(h, Lx, k, distance, p, draws, seed, trial_begin, trial_end,
+                               h->d_prior.p, max_iter, variant, alpha, damping, clip_llr, flags,
+                               reinterpret_cast<int64_t*>(h->d_counters.p), s);
+    if (rc) return rc;
+    long long tmp[qbp::NUM_COUNTERS];
+    HIP_TRY(hipMemcpyAsync(tmp, h->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < qbp::NUM_COUNTERS; ++i) counters[i] += tmp[i];
+    return QBP_OK;
+}
+
+int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
+                         int64_t trial_begin, int64_t T, uint8_t* errors)
+{
+    int rc = check_decode_args(h, T, 1, 0);
+    if (rc) return rc;
+    if (!errors) return fail(QBP_E_INVALID, "errors is null");
+    if (draws != 1 && draws != 2) return fail(QBP_E_INVALID, "draws must be 1 or 2");
+    if (T == 0) return QBP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    rc = mc_prepare(h, nullptr, 0, s);
+    if (rc) return rc;
+    const size_t n = h->n;
+    HIP_TRY(h->d_hard.reserve((size_t)T * n));
+    HIP_TRY(h->d_prior.reserve(n));
+    HIP_TRY(h->d_counters.reserve(qbp::NUM_COUNTERS));
+    std::vector<double> prior(n, 1.0);
+    HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, qbp::NUM_COUNTERS * sizeof(long long), s));
+    LaunchCfg cfg;
+    rc = make_cfg(h, T, &cfg);
+    if (rc) return rc;
+    FusedParams P{};
+    fill_static(h, P, cfg);
+    P.prior = h->d_prior.p; P.B = T; P.max_iter = 1; P.flags = 0;
+    P.alpha = 1.0; P.damping = 1.0; P.clip_llr = 20.0;
+    P.lx_cols = h->d_lx_cols.p; P.trial_begin = trial_begin; P.seed = seed;
+    P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = 0;
+    P.counters = h->d_counters.p; P.errors_out = h->d_hard.p;
+    HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
+    HIP_TRY(launch_variant<true>(QBP_MIN_SUM, P, cfg, s));
+    HIP_TRY(hipMemcpyAsync(errors, h->d_hard.p, (size_t)T * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return QBP_OK;
+}
+
+int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
+{
+    if (!h) return fail(QBP_E_INVALID, "null handle");
+    switch (option) {
+        case QBP_OPT_SLOTS_PER_BLOCK:
+            if (value < 0 || value * h->m > 1024) return fail(QBP_E_INVALID, "slots*m must be <= 1024");
+            h->opt_slots = (int)value; return QBP_OK;
+        case QBP_OPT_BLOCKS_PER_CU:
+            if (value < 0 || value > 32) return fail(QBP_E_INVALID, "blocks per CU out of range");
+            h->opt_blocks_per_cu = (int)value; return QBP_OK;
+        default: return fail(QBP_E_INVALID, "unknown option %d", option);
+    }
+}
+
+int64_t qbp_get_info(qbp_handle* h, int32_t what)
+{
+    if (!h) return -1;
+    switch (what) {
+        case QBP_INFO_M: return h->m;
+        case QBP_INFO_N: return h->n;
+        case QBP_INFO_EDGES: return h->E;
+        case QBP_INFO_MAX_ROW_DEG: return h->max_row_deg;
+        case QBP_INFO_MAX_COL_DEG: return h->max_col_deg;
+        case QBP_INFO_KERNEL_KIND: return h->fused_ok ? 1 : 2;
+        case QBP_INFO_THREADS: return h->last_threads;
+        case QBP_INFO_LDS_BYTES: return h->last_lds;
+        case QBP_INFO_GRID: return h->last_grid;
+        case QBP_INFO_NUM_CU: return h->num_cu;
+        default: return -1;
+    }
+}
+
+int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int64_t count)
+{
+    if (!h || !x || !y || count < 0 || kind < 0 || kind > 1) return fail(QBP_E_INVALID, "bad arguments");
+    if (count == 0) return QBP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(h->d_mathx.reserve((size_t)count));
+    HIP_TRY(h->d_mathy.reserve((size_t)count));
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->d_mathx.p, x, (size_t)count * sizeof(double), hipMemcpyHostToDevice, s));
+    const int threads = 256;
+    const long long blocks = (count + threads - 1) / threads;
+    hipLaunchKernelGGL(qbp::debug_math_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, kind,
+                       h->d_mathx.p, h->d_mathy.p, (long long)count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(y, h->d_mathy.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return QBP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,422 @@
+// Fused on-chip belief-propagation kernel for gfx950 (MI355X).
+//
+// One lane per CHECK node.  A workgroup decodes S syndromes concurrently ("slots"); slot s owns
+// lanes [s*m, (s+1)*m).  A lane keeps its check's d_c variable->check messages Q in registers
+// for the whole decode; the only data exchanged between lanes are the check->variable messages
+// R, one double per edge, staged in LDS ([slot][edge j of the row][check c]: consecutive lanes
+// write consecutive addresses).  Per BP iteration a lane
+//   1. check step:   t_j = tanh(Q_j/2); row product; R_j = 2 atanh(clip(prod / t_j * sign))
+//                    -> ds_write R_j                          (beliefPropagation.py:114-126)
+//   2. barrier
+//   3. variable step, done redundantly by every check lane for its own d_c variables: reads the
+//      <= DV messages of each variable's column from LDS (ascending check order, the order
+//      np.sum(R, axis=0) accumulates in), value_j = sum + prior_j, Q_j = value_j - R_j, hard
+//      bit, parity of the row vs the syndrome bit -> per-slot "unsatisfied" flag (:129-139)
+//   4. barrier, read the flag: converged / iteration limit -> emit outputs, fetch next syndrome.
+// No message ever touches HBM: per syndrome the kernel reads m syndrome bytes and writes
+// n hard bytes + n LLR doubles + 5 bytes.  Slots fetch work from a global atomic counter, so a
+// slot whose syndrome converges early (reference semantics: return at the first syndrome match)
+// immediately starts the next one, independent of its neighbours.
+//
+// Irregular rows/columns are padded: a missing edge has prior = +inf (its Q stays +inf, its tanh
+// is exactly 1.0, its hard bit 0), a missing column entry points at a per-slot LDS word that
+// holds 0.0 (x + 0.0 is exact) -- the kernel body has no degree-dependent branches.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qbp_math.hpp"
+
+namespace qbp {
+
+constexpr int NUM_COUNTERS = 12;
+
+struct FusedParams {
+    // problem
+    const uint8_t* syndromes;   // [B][m] (decode mode)
+    const double* prior;        // [n]
+    long long B;                // syndromes / trials in this launch
+    int m, n;
+    int S;                      // slots per workgroup
+    int slot_stride;            // doubles per slot in LDS (DC*m + 2)
+    int max_iter;
+    unsigned flags;
+    int padded;                 // some row has fewer than DC edges (irregular H)
+    double alpha, damping, clip_llr;
+    // outputs (decode mode; may be null)
+    uint8_t* hard;
+    uint8_t* converged;
+    int32_t* iters;
+    double* llr;
+    // static tables of the code
+    const int32_t* tab_var;     // [DC][m]   variable of edge j of check c, -1 = padding
+    const uint16_t* tab_nbr;    // [DC][DV][m] LDS word offsets of the column of that variable
+    const uint32_t* tab_writer; // [m] bit j: edge (c, j) is the first of its column
+    const int32_t* iso_vars;    // variables with no check
+    int n_iso;
+    // work distribution
+    unsigned long long* work_counter;   // zeroed before launch
+    // Monte-Carlo mode
+    const unsigned long long* lx_cols;  // [n] bit l = Lx[l][v]
+    long long trial_begin;
+    unsigned long long seed;
+    unsigned threshold;         // floor(p * 2^32)
+    int draws;
+    int half_distance;          // distance // 2
+    long long* counters;        // [NUM_COUNTERS], atomically added
+    uint8_t* errors_out;        // optional [B][n] dump of sampled errors (tests)
+};
+
+__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// Error bit of qubit v in trial `trial` (specification: oracle/bp_oracle.c, oracle_mc_errors).
+__device__ __forceinline__ unsigned mc_error_bit(unsigned long long trial, int v, int draws,
+                                                 unsigned long long seed, unsigned thr)
+{
+    unsigned bit = 0;
+    for (int d = 0; d < draws; ++d) {
+        unsigned c[4] = {(unsigned)trial, (unsigned)(trial >> 32), (unsigned)(v >> 2), (unsigned)d};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        const unsigned w = (v & 3) == 0 ? c[0] : (v & 3) == 1 ? c[1] : (v & 3) == 2 ? c[2] : c[3];
+        bit ^= (w < thr) ? 1u : 0u;
+    }
+    return bit;
+}
+
+__device__ __forceinline__ double clipd(double x, double lo, double hi)
+{   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi)
+    const double y = x < lo ? lo : x;
+    return y > hi ? hi : y;
+}
+
+// LDS carve (in units of 8 bytes after the message area):
+//   [S]  next work index per slot
+//   [S]  MC logical-mask accumulator
+//   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count
+template <int DC, int DV, int VARIANT, bool MC, int MAX_THREADS>
+__global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams P)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const int m = P.m;
+    const int S = P.S;
+    const int slot = tid / m;
+    const int c = tid - slot * m;
+    const bool lane_valid = slot < S;
+    const bool leader = lane_valid && c == 0;
+    const int sl = lane_valid ? slot : 0;
+
+    double* const Rs = smem + (size_t)sl * P.slot_stride;
+    const int zoff = DC * m;
+    long long* const next_work = reinterpret_cast<long long*>(smem + (size_t)S * P.slot_stride);
+    unsigned long long* const mc_lmask = reinterpret_cast<unsigned long long*>(next_work + S);
+    int* const words = reinterpret_cast<int*>(mc_lmask + S);
+    int* const flag0 = words;            // [2][S]
+    int* const mc_weight = words + 2 * S;
+    int* const mc_diff = words + 3 * S;
+    int* const active_count = words + 4 * S;
+
+    // ---- per-lane static tables (registers for the whole kernel) ---------------------------
+    int var[DC];
+    double pri[DC];
+    unsigned short nbr[DC][DV];
+    unsigned wmask = 0;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        var[j] = lane_valid ? P.tab_var[j * m + c] : -1;
+        pri[j] = var[j] >= 0 ? P.prior[var[j]] : __builtin_inf();
+#pragma unroll
+        for (int k = 0; k < DV; ++k)
+            nbr[j][k] = lane_valid ? P.tab_nbr[(j * DV + k) * m + c] : (unsigned short)zoff;
+    }
+    if (lane_valid) wmask = P.tab_writer[c];
+
+    const long long B = P.B;
+    const long long total_slots = (long long)gridDim.x * S;
+    const bool force_full = (P.flags & 1u) != 0;
+    const double one_minus_damping = 1.0 - P.damping;
+    const int max_iter = P.max_iter;
+
+    long long b = lane_valid ? (long long)blockIdx.x * S + slot : B;
+    bool active = b < B;
+
+    if (leader) {
+        Rs[zoff] = 0.0;
+        flag0[slot] = 0;
+        flag0[S + slot] = 0;
+        mc_lmask[slot] = 0ull;
+        mc_weight[slot] = 0;
+        mc_diff[slot] = 0;
+        next_work[slot] = total_slots + (long long)atomicAdd(P.work_counter, 1ull);
+    }
+    if (tid == 0) {
+        long long first = (long long)blockIdx.x * S;
+        long long cnt = B - first;
+        *active_count = (int)(cnt < 0 ? 0 : (cnt > S ? S : cnt));
+    }
+
+    // ---- per-syndrome state ---------------------------------------------------------------
+    double Q[DC];
+    double R[DC];
+    unsigned sbit = 0, ebits = 0;
+    int it = 0;
+    bool frozen = false;
+
+    auto start_syndrome = [&]() {
+        it = 0;
+        frozen = false;
+#pragma unroll
+        for (int j = 0; j < DC; ++j) Q[j] = pri[j];      // Q = where(mask, initialBelief, 0)
+        if constexpr (MC) {
+            const unsigned long long trial = (unsigned long long)(P.trial_begin + b);
+            ebits = 0;
+#pragma unroll
+            for (int j = 0; j < DC; ++j)
+                if (var[j] >= 0)
+                    ebits |= mc_error_bit(trial, var[j], P.draws, P.seed, P.threshold) << j;
+            sbit = __builtin_popcount(ebits) & 1u;       // syndrome = H e mod 2
+        } else {
+            sbit = P.syndromes[b * m + c] & 1u;
+        }
+    };
+    if (active) start_syndrome();
+    __syncthreads();
+
+    // leader-only bookkeeping
+    bool refill = false;
+    bool mc_pending = false;
+    int mc_pending_conv = 0, mc_pending_it = 0;
+    long long cnt_local[NUM_COUNTERS];
+    if constexpr (MC) {
+#pragma unroll
+        for (int i = 0; i < NUM_COUNTERS; ++i) cnt_local[i] = 0;
+    }
+
+    for (unsigned phase = 0;; ++phase) {
+        // ================= check step =======================================================
+        if (active) {
+            if constexpr (VARIANT == 2) {
+                // rework/decoding.py:28-56
+                double sprod = 1.0, min1 = __builtin_inf();
+                int min1_j = 0;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    const double s = Q[j] < 0.0 ? -1.0 : 1.0;   // sign, 0 -> +1, padding +1
+                    sprod *= s;
+                    const double a = __builtin_fabs(Q[j]);
+                    if (a < min1) { min1 = a; min1_j = j; }       // first occurrence
+                }
+                double min2 = __builtin_inf();
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    const double a = __builtin_fabs(Q[j]);
+                    if (j != min1_j && a < min2) min2 = a;
+                }
+                const double as = sbit ? -P.alpha : P.alpha;      // alpha * syndrome_sign
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    const double s = Q[j] < 0.0 ? -1.0 : 1.0;
+                    const double mag = (__builtin_fabs(Q[j]) == min1) ? min2 : min1;
+                    R[j] = (as * (sprod * s)) * mag;
+                }
+            } else {
+                double t[DC];
+                double prod;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    t[j] = tanh_half(Q[j]);
+                    prod = (j == 0) ? t[0] : prod * t[j];         // np.prod, ascending column
+                }
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+                    double po = prod / ts;                        // IEEE division, as numpy
+                    po = sbit ? -po : po;                         // * syndrome_sign
+                    const double r = atanh2(clipd(po, -0.9999999, 0.9999999));
+                    R[j] = (VARIANT == 1) ? r * P.alpha : r;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DC; ++j) Rs[j * m + c] = R[j];
+        }
+        __syncthreads();                                          // B1
+        if (*active_count == 0) break;
+
+        // ================= variable step (per edge of this check) ============================
+        double val[DC];
+        unsigned hbits = 0;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                double s = Rs[nbr[j][0]];
+#pragma unroll
+                for (int k = 1; k < DV; ++k) s = s + Rs[nbr[j][k]];   // ascending check order
+                val[j] = s + pri[j];
+                hbits |= (val[j] < 0.0 ? 1u : 0u) << j;
+                const double qn = val[j] - R[j];
+                if constexpr (VARIANT == 0) {
+                    Q[j] = qn;
+                } else {
+                    const double q = P.damping * qn + one_minus_damping * Q[j];
+                    Q[j] = clipd(q, -P.clip_llr, P.clip_llr);
+                }
+            }
+            if (P.padded) {                                       // wave-uniform branch
+#pragma unroll
+                for (int j = 0; j < DC; ++j)
+                    if (var[j] < 0) Q[j] = __builtin_inf();       // padding stays neutral
+            }
+            const unsigned unsat = (__builtin_popcount(hbits) & 1u) ^ sbit;
+            if (unsat) flag0[(phase & 1u) * S + slot] = 1;
+        }
+        if (leader) {
+            flag0[((phase + 1u) & 1u) * S + slot] = 0;
+            if (refill) {
+                next_work[slot] = total_slots + (long long)atomicAdd(P.work_counter, 1ull);
+                refill = false;
+            }
+            if constexpr (MC) {
+                if (mc_pending) {
+                    // classification of the trial emitted in the previous phase
+                    // (paperResults_GPU.py:127-144, BP only)
+                    const unsigned long long lm = mc_lmask[slot];
+                    const int ew = mc_weight[slot];
+                    const int df = mc_diff[slot];
+                    mc_lmask[slot] = 0ull; mc_weight[slot] = 0; mc_diff[slot] = 0;
+                    const bool logical = lm != 0ull;
+                    cnt_local[0] += 1;
+                    if (mc_pending_conv && !logical && df) cnt_local[5] += 1;
+                    if (logical) {
+                        cnt_local[1] += 1;
+                        if (ew < P.half_distance) cnt_local[3] += 1; else cnt_local[4] += 1;
+                        if (!mc_pending_conv) cnt_local[8] += 1;
+                    }
+                    if (!mc_pending_conv) cnt_local[6] += 1;
+                    cnt_local[7] += mc_pending_it;
+                    if (!df) cnt_local[9] += 1;
+                    mc_pending = false;
+                }
+            }
+        }
+        __syncthreads();                                          // B2
+
+        // ================= convergence / output / next syndrome ==============================
+        if (active) {
+            const bool conv = flag0[(phase & 1u) * S + slot] == 0;
+            const bool last = it == max_iter - 1;
+            if (!frozen && (conv || last)) {
+                if constexpr (MC) {
+                    unsigned long long lm = 0ull;
+                    int ew = 0;
+                    unsigned df = 0;
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        if ((wmask >> j) & 1u) {
+                            const unsigned e = (ebits >> j) & 1u;
+                            const unsigned res = ((hbits >> j) & 1u) ^ e;
+                            ew += (int)e;
+                            df |= res;
+                            if (res) lm ^= P.lx_cols[var[j]];
+                            if (P.errors_out) P.errors_out[b * P.n + var[j]] = (uint8_t)e;
+                        }
+                    }
+                    for (int i = c; i < P.n_iso; i += m) {
+                        const int v = P.iso_vars[i];
+                        const unsigned e = mc_error_bit((unsigned long long)(P.trial_begin + b), v,
+                                                        P.draws, P.seed, P.threshold);
+                        const unsigned res = (P.prior[v] < 0.0 ? 1u : 0u) ^ e;
+                        ew += (int)e;
+                        df |= res;
+                        if (res) lm ^= P.lx_cols[v];
+                        if (P.errors_out) P.errors_out[b * P.n + v] = (uint8_t)e;
+                    }
+                    if (lm) atomicXor(&mc_lmask[slot], lm);
+                    if (ew) atomicAdd(&mc_weight[slot], ew);
+                    if (df) atomicOr(&mc_diff[slot], 1);
+                    if (c == 0) { mc_pending = true; mc_pending_conv = conv; mc_pending_it = it; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        if ((wmask >> j) & 1u) {
+                            const long long o = b * P.n + var[j];
+                            if (P.llr) P.llr[o] = val[j];
+                            if (P.hard) P.hard[o] = (uint8_t)((hbits >> j) & 1u);
+                        }
+                    }
+                    for (int i = c; i < P.n_iso; i += m) {
+                        const int v = P.iso_vars[i];
+                        const double pv = P.prior[v];
+                        if (P.llr) P.llr[b * P.n + v] = pv;
+                        if (P.hard) P.hard[b * P.n + v] = pv < 0.0;
+                    }
+                    if (c == 0) {
+                        if (P.converged) P.converged[b] = conv;
+                        if (P.iters) P.iters[b] = it;
+                    }
+                }
+            }
+            if (conv) frozen = true;
+            const bool finished = last || (conv && !force_full);
+            if (finished) {
+                b = next_work[slot];
+                if (c == 0) refill = true;
+                if (b < B) {
+                    start_syndrome();
+                } else {
+                    active = false;
+                    if (c == 0) atomicSub(active_count, 1);
+                }
+            } else {
+                ++it;
+            }
+        }
+    }
+
+    if constexpr (MC) {
+        if (leader) {
+            // the last emitted trial of this slot may still be pending (emitted after B2 of the
+            // final phase; everybody passed B1 since, so the accumulators are complete)
+            if (mc_pending) {
+                const unsigned long long lm = mc_lmask[slot];
+                const int ew = mc_weight[slot];
+                const int df = mc_diff[slot];
+                const bool logical = lm != 0ull;
+                cnt_local[0] += 1;
+                if (mc_pending_conv && !logical && df) cnt_local[5] += 1;
+                if (logical) {
+                    cnt_local[1] += 1;
+                    if (ew < P.half_distance) cnt_local[3] += 1; else cnt_local[4] += 1;
+                    if (!mc_pending_conv) cnt_local[8] += 1;
+                }
+                if (!mc_pending_conv) cnt_local[6] += 1;
+                cnt_local[7] += mc_pending_it;
+                if (!df) cnt_local[9] += 1;
+            }
+#pragma unroll
+            for (int i = 0; i < NUM_COUNTERS; ++i)
+                if (cnt_local[i])
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i),
+                              (unsigned long long)cnt_local[i]);
+        }
+    }
+}
+
+// Device evaluation of the math functions (accuracy tests).
+__global__ void debug_math_kernel(int kind, const double* x, double* y, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = kind == 0 ? tanh_half(x[i]) : atanh2(x[i]);
+}
+
+}  // namespace qbp

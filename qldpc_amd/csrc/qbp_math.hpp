@@ -1,0 +1,132 @@
+// FP64 elementary functions of the BP check-node update, written for the gfx950 vector ALU.
+//
+// The reference computes, per edge and iteration (decoding/beliefPropagation.py:114-126):
+//     t = np.tanh(Q * 0.5)   ...   R = 2.0 * np.arctanh(clip(prod / t, +-0.9999999))
+// gfx950 has no FP64 exp/log instruction, and the ROCm device-library tanh()/atanh() spend
+// most of their instructions on argument ranges this path never sees.  These two functions
+// are the same mathematical functions, accurate to about 1 ulp (tests/test_math_cpu.py checks
+// them against mpmath on the host build; tests/test_gpu_math.py on the device), built from:
+//   * one v_rcp_f64 + Newton division each (operands are always normal: no v_div_scale /
+//     v_div_fixup range handling needed),
+//   * tanh(q/2) = (1 - E) / (1 + E), E = exp(-|q|) = 2^k (1 + p): argument reduction by ln2,
+//     an 11-term polynomial for p = expm1(r), numerator and denominator formed by one fma
+//     each around the exact constants 1 -+ 2^k (no cancellation for small |q|: k = 0 gives -p),
+//   * 2 atanh(y) = log((1+y)/(1-y)) = e ln2 + 2 atanh(s), s = (N - 2^e D) / (N + 2^e D),
+//     N = 1 + |y|, D = 1 - |y|: ONE division instead of the two of log1p(2y/(1-y)), and
+//     s == |y| exactly when e == 0 (small messages keep full relative accuracy).
+// Coefficients: tools/fit_math_coeffs.py (mpmath near-minimax fits).
+//
+// The header also compiles on the host (plain C++), where the reciprocal seed is 1.0 / b:
+// that build exists only so the CPU test suite can measure the ulp error without a GPU.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QBP_HD __device__ __forceinline__
+#define QBP_RCP(x) __builtin_amdgcn_rcp(x)
+#define QBP_LDEXP(x, e) __builtin_amdgcn_ldexp(x, e)
+#define QBP_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
+#define QBP_RINT(x) __builtin_rint(x)
+#elif defined(__HIPCC__)
+#define QBP_HD __host__ __device__ inline
+#define QBP_RCP(x) (1.0 / (x))
+#define QBP_LDEXP(x, e) std::ldexp(x, e)
+#define QBP_FREXP_EXP(x) (std::ilogb(x) + 1)
+#define QBP_RINT(x) std::nearbyint(x)
+#else
+#define QBP_HD inline
+#define QBP_RCP(x) (1.0 / (x))
+#define QBP_LDEXP(x, e) std::ldexp(x, e)
+#define QBP_FREXP_EXP(x) (std::ilogb(x) + 1)
+#define QBP_RINT(x) std::nearbyint(x)
+#endif
+
+namespace qbp {
+
+// a / b for normal b with a / b neither overflowing nor subnormal: reciprocal seed, two
+// Newton steps, one residual correction (the core of the IEEE sequence, without scaling).
+QBP_HD double div_nr(double a, double b)
+{
+    double r = QBP_RCP(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = a * r;
+    double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
+}
+
+// tanh(q * 0.5), any finite or infinite q.
+QBP_HD double tanh_half(double q)
+{
+    constexpr double INV_LN2 = 0x1.71547652b82fep+0;
+    constexpr double LN2_HI = 0x1.62e42f8000000p-1;   // 26 significant bits: k * LN2_HI exact
+    constexpr double LN2_LO = 0x1.be8e7bcd5e4f2p-27;
+    double a = __builtin_fabs(q);
+    a = a < 40.0 ? a : 40.0;               // tanh(20) already rounds to 1; also maps inf
+    const double x = -a;                   // em = expm1(x), x in [-40, 0]
+    const double kd = QBP_RINT(x * INV_LN2);
+    double r = __builtin_fma(-kd, LN2_HI, x);
+    r = __builtin_fma(-kd, LN2_LO, r);     // |r| <= ln2/2 (+ rounding slack)
+    double P = 0x1.1f7861ab0e5c1p-29;
+    P = __builtin_fma(P, r, 0x1.af574f448311ap-26);
+    P = __builtin_fma(P, r, 0x1.27e4d8c2b2e6cp-22);
+    P = __builtin_fma(P, r, 0x1.71ddfd9647581p-19);
+    P = __builtin_fma(P, r, 0x1.a01a01a7b14bbp-16);
+    P = __builtin_fma(P, r, 0x1.a01a01ad6369dp-13);
+    P = __builtin_fma(P, r, 0x1.6c16c16c1613fp-10);
+    P = __builtin_fma(P, r, 0x1.111111110fe17p-7);
+    P = __builtin_fma(P, r, 0x1.5555555555556p-5);
+    P = __builtin_fma(P, r, 0x1.5555555555557p-3);
+    P = __builtin_fma(P, r, 0x1.0000000000000p-1);
+    const double p = __builtin_fma(r * r, P, r);          // expm1(r)
+    const double s = QBP_LDEXP(1.0, (int)kd);             // 2^k, k in [-58, 0]
+    // E = e^-a = s (1 + p);  tanh(a/2) = (1 - E) / (1 + E).  (1 -+ s) are exact, so numerator
+    // and denominator each carry a single rounding.
+    const double num = __builtin_fma(-s, p, 1.0 - s);     // in [0, 1]
+    const double den = __builtin_fma(s, p, 1.0 + s);      // in [1, 2]
+    const double t = div_nr(num, den);
+    return __builtin_copysign(t, q);
+}
+
+// 2 * atanh(y) for |y| < 1 (the caller has clipped to |y| <= 0.9999999).
+QBP_HD double atanh2(double y)
+{
+    constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;
+    constexpr double LN2_HI = 0x1.62e42f8000000p-1;
+    constexpr double LN2_LO = 0x1.be8e7bcd5e4f2p-27;
+    const double a = __builtin_fabs(y);
+    const double N = 1.0 + a;                     // in [1, 2)
+    const double D = 1.0 - a;                     // in (0, 1]
+    const double N_lo = a - (N - 1.0);            // exact rounding error of N  (1 >= a)
+    const double D_lo = (1.0 - D) - a;            // exact rounding error of D
+    // e: (N / D) * 2^-e in [1/sqrt2, sqrt2)
+    const int e0 = 1 - QBP_FREXP_EXP(D);          // D * 2^e0 in [1, 2)
+    const double Dm = QBP_LDEXP(D, e0);
+    int e = e0;
+    e += (N >= SQRT2 * Dm) ? 1 : 0;
+    e -= (N * SQRT2 < Dm) ? 1 : 0;
+    const double Ds = QBP_LDEXP(D, e);
+    const double Ds_lo = QBP_LDEXP(D_lo, e);
+    const double num = (N - Ds) + (N_lo - Ds_lo); // e == 0: (2a) + 0 exactly
+    const double den = N + Ds;                    // e == 0: 2 exactly
+    const double s = div_nr(num, den);            // |s| <= 0.1716
+    const double z = s * s;
+    double L = 0x1.2c7878482df85p-3;
+    L = __builtin_fma(L, z, 0x1.39e6974a2f9f4p-3);
+    L = __builtin_fma(L, z, 0x1.74636f948ce07p-3);
+    L = __builtin_fma(L, z, 0x1.c71c6047521e3p-3);
+    L = __builtin_fma(L, z, 0x1.24924930099b8p-2);
+    L = __builtin_fma(L, z, 0x1.9999999993f92p-2);
+    L = __builtin_fma(L, z, 0x1.5555555555559p-1);
+    const double ed = (double)e;
+    double tail = __builtin_fma(s * z, L, ed * LN2_LO);   // s z L(z) + e ln2_lo
+    tail = __builtin_fma(2.0, s, tail);                   // + 2 s
+    const double res = __builtin_fma(ed, LN2_HI, tail);   // + e ln2_hi (exact product)
+    return __builtin_copysign(res, y);
+}
+
+}  // namespace qbp

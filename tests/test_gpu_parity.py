@@ -1,0 +1,134 @@
+"""GPU: the HIP decoder, called through the C ABI, against (1) the golden vectors produced by
+the real reference and (2) the CPU oracle on fresh seeded inputs."""
+import numpy as np
+import pytest
+
+import golden_util
+from oracle import oracle
+from qldpc_amd import _lib, bp, codes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", golden_util.TAGS)
+def test_hip_matches_reference_goldens(tag):
+    n_cases, worst = 0, (0.0, 0.0)
+    for case in golden_util.load(tag):
+        dec = bp.decoder_for(case["H"])
+        assert dec.info("kernel_kind") == 1
+        hard, conv, iters, llr = dec.decode(case["syndromes"], case["prior"], case["max_iter"],
+                                            case["variant"], case["alpha"], case["damping"],
+                                            case["clip_llr"])
+        w = golden_util.compare(case, hard, conv, iters, llr, "hip")
+        worst = (max(worst[0], w[0]), max(worst[1], w[1]))
+        n_cases += 1
+    assert n_cases >= 10
+    print(f"{tag}: {n_cases} cases; worst LLR rel err converged {worst[0]:.2e}, "
+          f"non-converged {worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("name,p,B", [("[[72, 12, 6]]", 0.01, 10000),      # BASELINE config 2
+                                      ("[[144, 12, 12]]", 0.05, 4000),
+                                      ("[[288, 12, 18]]", 0.05, 3000),
+                                      ("[[288, 12, 18]]", 0.01, 3000)])
+def test_hip_vs_oracle_fresh(name, p, B):
+    code = codes.load_code(name)
+    rng = np.random.default_rng(hash((name, p)) % 2**32)
+    errors = (rng.random((B, code.n)) < p).astype(np.uint8)
+    syn = (errors @ code.Hx.T % 2).astype(np.uint8)
+    prior = np.full(code.n, np.log((1 - p) / p))
+    dec = bp.decoder_for(code.Hx)
+    hard, conv, iters, llr = dec.decode(syn, prior, 50)
+    o_hard, o_conv, o_iters, o_llr = oracle.decode_batch(code.Hx, syn, prior, 50)
+    assert np.array_equal(conv, o_conv)
+    assert np.array_equal(iters, o_iters)
+    assert np.array_equal(hard, o_hard)
+    rel = np.abs(llr - o_llr) / np.maximum(np.abs(o_llr), 1e-300)
+    assert rel[conv].max() <= 1e-5          # BASELINE.json: posterior LLRs within 1e-5 relative
+    # converged => H . hard == syndrome (size-independent property)
+    assert np.array_equal((hard[conv].astype(np.int64) @ code.Hx.T) % 2, syn[conv])
+    print(f"{name} p={p}: {int(conv.sum())}/{B} converged, mean iters {iters.mean():.2f}, "
+          f"max rel LLR err (converged) {rel[conv].max():.2e}")
+
+
+def test_force_full_same_outputs_and_determinism():
+    code = codes.load_code("[[144, 12, 12]]")
+    rng = np.random.default_rng(3)
+    p = 0.06
+    syn = ((rng.random((2000, code.n)) < p).astype(np.uint8) @ code.Hx.T % 2).astype(np.uint8)
+    prior = np.full(code.n, np.log((1 - p) / p))
+    dec = bp.decoder_for(code.Hx)
+    a = dec.decode(syn, prior, 50)
+    b = dec.decode(syn, prior, 50, flags=_lib.FLAG_FORCE_FULL)
+    c = dec.decode(syn, prior, 50)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
+def test_min_sum_and_damped_vs_oracle():
+    code = codes.load_code("[[144, 12, 12]]")       # BASELINE config 3 parameterisation
+    rng = np.random.default_rng(4)
+    p = 0.05
+    syn = ((rng.random((3000, code.n)) < p).astype(np.uint8) @ code.Hx.T % 2).astype(np.uint8)
+    prior = np.full(code.n, np.log((1 - p) / p))
+    dec = bp.decoder_for(code.Hx)
+    for variant, kw in ((_lib.MIN_SUM, dict(alpha=0.8, damping=0.7, clip_llr=25.0)),
+                        (_lib.DAMPED_SP, dict(alpha=1.0, damping=0.8, clip_llr=20.0))):
+        hard, conv, iters, llr = dec.decode(syn, prior, 50, variant, **kw)
+        o = oracle.decode_batch(code.Hx, syn, prior, 50, variant, **kw)
+        assert np.array_equal(conv, o[1]) and np.array_equal(iters, o[2])
+        assert np.array_equal(hard, o[0])
+        if variant == _lib.MIN_SUM:     # no transcendental: every LLR must be bit-identical
+            assert np.array_equal(llr, o[3])
+        else:
+            rel = np.abs(llr - o[3]) / np.maximum(np.abs(o[3]), 1e-300)
+            assert rel[conv].max() <= 1e-5
+
+
+def test_edge_cases():
+    code = codes.load_code("[[72, 12, 6]]")
+    dec = bp.decoder_for(code.Hx)
+    prior = np.full(code.n, np.log(0.95 / 0.05))
+    # empty batch
+    hard, conv, iters, llr = dec.decode(np.zeros((0, 36), np.uint8), prior, 50)
+    assert hard.shape == (0, 72) and conv.shape == (0,)
+    # zero syndrome -> converged at iteration 0, hard = 0
+    hard, conv, iters, llr = dec.decode(np.zeros((5, 36), np.uint8), prior, 50)
+    assert conv.all() and not hard.any() and (iters == 0).all()
+    # B = 1 and a ragged batch size (not a multiple of the slots per workgroup)
+    syn = ((np.random.default_rng(0).random((37, 72)) < 0.05).astype(np.uint8) @ code.Hx.T % 2)
+    a = dec.decode(syn.astype(np.uint8), prior, 50)
+    for i in (0, 36):
+        b = dec.decode(syn[i:i + 1].astype(np.uint8), prior, 50)
+        assert np.array_equal(a[0][i], b[0][0]) and a[2][i] == b[2][0]
+        assert np.array_equal(a[3][i], b[3][0])
+    # argument errors
+    with pytest.raises(_lib.QbpError):
+        dec.decode(syn.astype(np.uint8), prior, 0)
+    with pytest.raises(ValueError):
+        dec.decode(syn[:, :10].astype(np.uint8), prior, 50)
+
+
+def test_reference_signatures_on_gpu(capsys):
+    """The shim functions: names, arity, dtypes, printed lines (beliefPropagation.py:28,82,141)."""
+    case = next(c for c in golden_util.load("steane") if c["note"] == "main.py")
+    H, s, prior = case["H"], case["syndromes"][0], list(case["prior"])
+    det, ok, llrs = bp.performBeliefPropagation(H, s, prior)
+    out = capsys.readouterr().out
+    assert "Initial syndrome: [1 1 0]" in out and "Error found at iteration 0: [0 0 1 0 0 0 0]" in out
+    assert det.dtype == np.int8 and ok is True and llrs.dtype == np.float64
+    assert det.tolist() == [0, 0, 1, 0, 0, 0, 0]
+    np.testing.assert_allclose(llrs, case["llr"][0], rtol=1e-9)
+    det2, ok2, llr2 = bp.performBeliefPropagationFast(H, s, prior, verbose=False, maxIter=50)
+    assert np.array_equal(det, det2) and np.array_equal(llrs, llr2)
+    from scipy.sparse import csr_matrix
+    det3, ok3, llr3 = bp.performBeliefPropagation(csr_matrix(H), s, prior, verbose=False)
+    assert np.array_equal(det, det3) and np.array_equal(llrs, llr3)
+    detb, convb, llrb = bp.performBeliefPropagationBatch(H, case["syndromes"], np.array(prior))
+    assert detb.dtype == np.int8 and convb.dtype == bool and detb.shape == (1, 7)
+    from qldpc_amd import rework
+    out4 = rework.performMinSum_Symmetric(H, s, prior, maxIter=50, alpha=0.8, damping=0.7,
+                                          clip_llr=25)
+    assert len(out4) == 4 and isinstance(out4[3], int)
+    with pytest.raises(ValueError):
+        bp.performBeliefPropagationFast(H, s, prior, verbose=False, maxIter=0)

@@ -1,0 +1,99 @@
+"""CPU: host logic and the C-ABI library surface (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from qldpc_amd import _lib, bp, codes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "qldpc_amd", "csrc"), "libqbp.so"])
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "qbp.h")).read()
+    declared = set(re.findall(r"\b(qbp_[a-z_]+)\s*\(", header))
+    declared.discard("qbp_handle")
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.qbp_version()
+
+
+def test_create_fails_loudly_without_gpu(lib):
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    code = codes.load_code("[[72, 12, 6]]")
+    with pytest.raises(_lib.QbpError, match="no CPU fallback"):
+        bp.performBeliefPropagationFast(code.Hx, np.zeros(36, int), [1.0] * 72, verbose=False)
+
+
+def test_argument_validation_before_device(lib):
+    h = C.c_void_p()
+    rp = np.array([0, 2], np.int32)
+    assert lib.qbp_create(rp.ctypes.data, np.array([1, 0], np.int32).ctypes.data, 1, 2, 0,
+                          C.byref(h)) == -1          # columns not ascending
+    assert b"ascending" in lib.qbp_last_error()
+    assert lib.qbp_create(rp.ctypes.data, np.array([0, 5], np.int32).ctypes.data, 1, 2, 0,
+                          C.byref(h)) == -1          # column out of range
+    assert lib.qbp_create(None, None, 1, 2, 0, C.byref(h)) == -1
+
+
+def test_csr_from_H_matches_scipy():
+    from scipy.sparse import csr_matrix
+    for name in ("steane", "[[72, 12, 6]]", "[[288, 12, 18]]"):
+        H = codes.load_code(name).Hx
+        rp, ci, m, n = bp.csr_from_H(H)
+        S = csr_matrix(H)
+        S.sort_indices()
+        assert np.array_equal(rp, S.indptr) and np.array_equal(ci, S.indices)
+        rp2, ci2, _, _ = bp.csr_from_H(csr_matrix(H.astype(float)))
+        assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    with pytest.raises(ValueError):
+        bp.csr_from_H(np.zeros(5))
+
+
+def test_input_checks():
+    with pytest.raises(ValueError):
+        bp._syndromes([0, 2, 1], 3, batch=False)
+    with pytest.raises(ValueError):
+        bp._syndromes([0, 1], 3, batch=False)
+    assert bp._syndromes(np.array([True, False, True]), 3, batch=False).tolist() == [1, 0, 1]
+    with pytest.raises(ValueError):
+        bp._prior([1.0, 2.0], 3)
+    with pytest.raises(ValueError):
+        bp._check_iter(0)
+
+
+def test_code_fixtures():
+    for name in codes.code_names():
+        c = codes.load_code(name)
+        assert set(c.Hx.sum(1)) == {6} and set(c.Hx.sum(0)) == {3}
+        assert not ((c.Hx @ c.Hz.T) % 2).any()              # CSS condition
+        assert not ((c.Hz @ c.Lx.T) % 2).any()              # logicals commute with Z checks
+        n, k = c.n, c.Lx.shape[0]
+        assert f"[[{n}, {k}, {c.distance}]]" == name
+
+
+def test_dropin_package_resolution(tmp_path):
+    """`decoding.beliefPropagation` must resolve to this build, `decoding.OSD` to a reference-like
+    namespace directory that sits earlier on sys.path (as when running the reference's scripts)."""
+    ref = tmp_path / "ref"
+    (ref / "decoding").mkdir(parents=True)
+    (ref / "decoding" / "OSD.py").write_text("def performOSD(*a):\n    return 'ref-osd'\n")
+    (ref / "decoding" / "beliefPropagation.py").write_text("raise RuntimeError('reference BP imported')\n")
+    script = ("import decoding.beliefPropagation as b, decoding.OSD as o\n"
+              "print(b.performBeliefPropagationFast.__module__, o.performOSD())\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "qldpc_amd", "dropin")]))
+    (ref / "run.py").write_text(script)
+    out = subprocess.check_output([sys.executable, str(ref / "run.py")], env=env, cwd=ref, text=True)
+    assert out.split() == ["qldpc_amd.bp", "ref-osd"]
