@@ -102,14 +102,16 @@ def sample_errors_and_syndromes(H, error_rate, batch_size, rng):
 
 
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
-                 "degenerateErrors", "not_converged", "sum_iterations")
+                 "degenerateErrors", "not_converged", "sum_iterations",
+                 "logical_error_not_converged", "exact_recoveries", "reserved0", "reserved1")
 
 
 def classify_trials(H, Lx, distance, errors, syndromes, detections, converged, iters):
-    """paperResults_GPU.py:113-144 without the OSD call (BP only): int64 counters[8]."""
+    """paperResults_GPU.py:113-144 without the OSD call (BP only): int64 counters[12]
+    (layout of include/qbp.h: the reference's five counters plus bookkeeping)."""
     H = np.asarray(H).astype(np.int64)
     Lx = np.asarray(Lx).astype(np.int64)
-    cnt = np.zeros(8, np.int64)
+    cnt = np.zeros(12, np.int64)
     for i in range(errors.shape[0]):
         error = errors[i].astype(np.int64)
         detection = detections[i].astype(np.int64)
@@ -124,7 +126,20 @@ def classify_trials(H, Lx, distance, errors, syndromes, detections, converged, i
                 cnt[3] += 1
             else:
                 cnt[4] += 1
+            cnt[8] += int(not converged[i])
+        cnt[9] += int(np.array_equal(detection, error))
         cnt[0] += 1
         cnt[6] += int(not converged[i])
         cnt[7] += int(iters[i])
     return cnt
+
+
+def mc_counters(H, Lx, distance, p, prior, trial_begin, trial_end, draws=1, seed=0, max_iter=50,
+                variant=0, alpha=1.0, damping=1.0, clip_llr=20.0):
+    """CPU statement of qbp_mc_run: Philox errors -> syndromes -> oracle decode -> classification."""
+    H = np.asarray(H).astype(np.int64)
+    errors = mc_errors(H.shape[1], p, draws, seed, trial_begin, trial_end - trial_begin)
+    syndromes = (errors.astype(np.int64) @ H.T % 2).astype(np.uint8)
+    hard, conv, iters, _ = decode_batch(H, syndromes, prior, max_iter, variant, alpha, damping,
+                                        clip_llr)
+    return classify_trials(H, Lx, distance, errors, syndromes, hard, conv, iters)

@@ -73,7 +73,7 @@ struct qbp_handle {
     int n_iso = 0;
     DevBuf<unsigned long long> d_work_counter;
     // options
-    int opt_slots = 0, opt_blocks_per_cu = 0;
+    int opt_slots = 0, opt_blocks_per_cu = 0, opt_reg_variant = 0;
     // last launch configuration (introspection)
     int last_threads = 0, last_lds = 0, last_grid = 0;
     // scratch for the host-pointer entry points
@@ -95,10 +95,10 @@ struct LaunchCfg {
     int S, threads, lds_bytes, grid, slot_stride;
 };
 
-template <int VARIANT, bool MC, int MAXT>
+template <int VARIANT, bool MC, int MAXT, int MINW = 1>
 hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
 {
-    auto kern = qbp::bp_fused_kernel<DC_FUSED, DV_FUSED, VARIANT, MC, MAXT>;
+    auto kern = qbp::bp_fused_kernel<DC_FUSED, DV_FUSED, VARIANT, MC, MAXT, MINW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
     if (e != hipSuccess) return e;
@@ -107,11 +107,17 @@ hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t st
 }
 
 template <bool MC>
-hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s)
+hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s,
+                          int reg_variant)
 {
-    const bool small = cfg.threads <= 640;
+    const bool small = cfg.threads <= 640 && reg_variant != 2;
     switch (variant) {
         case QBP_SUM_PRODUCT:
+            if constexpr (!MC) {
+                // register-budget builds of the headline kernel (tuning: QBP_OPT_REG_VARIANT)
+                if (reg_variant == 3 && cfg.threads <= 640) return launch_one<0, MC, 640, 5>(P, cfg, s);
+                if (reg_variant == 4 && cfg.threads <= 640) return launch_one<0, MC, 640, 4>(P, cfg, s);
+            }
             return small ? launch_one<0, MC, 640>(P, cfg, s) : launch_one<0, MC, 1024>(P, cfg, s);
         case QBP_DAMPED_SP:
             return small ? launch_one<1, MC, 640>(P, cfg, s) : launch_one<1, MC, 1024>(P, cfg, s);
@@ -130,7 +136,8 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     cfg->S = S;
     cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
     cfg->slot_stride = DC_FUSED * m + 2;
-    size_t lds = ((size_t)S * cfg->slot_stride + 2 * (size_t)S) * 8 + (4 * (size_t)S + 1) * 4;
+    size_t lds = ((size_t)S * cfg->slot_stride + 2 * (size_t)S) * 8 +
+                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS) * 4;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
     cfg->lds_bytes = (int)lds;
@@ -312,7 +319,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     P.alpha = alpha; P.damping = damping; P.clip_llr = clip_llr;
     P.hard = d_hard; P.converged = d_converged; P.iters = d_iters; P.llr = d_llr;
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<false>(variant, P, cfg, s));
+    HIP_TRY(launch_variant<false>(variant, P, cfg, s, h->opt_reg_variant));
     return QBP_OK;
 }
 
@@ -407,7 +414,7 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
     P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = distance / 2;
     P.counters = reinterpret_cast<long long*>(d_counters);
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<true>(variant, P, cfg, s));
+    HIP_TRY(launch_variant<true>(variant, P, cfg, s, h->opt_reg_variant));
     return QBP_OK;
 }
 
@@ -465,7 +472,7 @@ int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
     P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = 0;
     P.counters = h->d_counters.p; P.errors_out = h->d_hard.p;
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<true>(QBP_MIN_SUM, P, cfg, s));
+    HIP_TRY(launch_variant<true>(QBP_MIN_SUM, P, cfg, s, 0));
     HIP_TRY(hipMemcpyAsync(errors, h->d_hard.p, (size_t)T * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
@@ -481,6 +488,9 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 32) return fail(QBP_E_INVALID, "blocks per CU out of range");
             h->opt_blocks_per_cu = (int)value; return QBP_OK;
+        case QBP_OPT_REG_VARIANT:
+            if (value < 0 || value > 4) return fail(QBP_E_INVALID, "register variant out of range");
+            h->opt_reg_variant = (int)value; return QBP_OK;
         default: return fail(QBP_E_INVALID, "unknown option %d", option);
     }
 }

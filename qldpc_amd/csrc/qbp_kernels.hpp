@@ -100,12 +100,36 @@ __device__ __forceinline__ double clipd(double x, double lo, double hi)
     return y > hi ? hi : y;
 }
 
+// Classification of one finished trial by its slot leader (paperResults_GPU.py:127-144 without
+// the OSD call): reads and clears the slot's accumulators, bumps the slot's counter row in LDS.
+__device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* mc_weight,
+                                            int* mc_diff, int* cnt, int slot, int conv, int it,
+                                            int half_distance)
+{
+    const unsigned long long lm = mc_lmask[slot];
+    const int ew = mc_weight[slot];
+    const int df = mc_diff[slot];
+    mc_lmask[slot] = 0ull; mc_weight[slot] = 0; mc_diff[slot] = 0;
+    const bool logical = lm != 0ull;                       // (Lx @ residual) % 2 has a 1
+    cnt[0] += 1;
+    if (conv && !logical && df) cnt[5] += 1;               // degenerateErrors  (:134-135)
+    if (logical) {
+        cnt[1] += 1;                                       // logical_error     (:137-138)
+        if (ew < half_distance) cnt[3] += 1; else cnt[4] += 1;   // (:140-144)
+        if (!conv) cnt[8] += 1;
+    }
+    if (!conv) cnt[6] += 1;
+    cnt[7] += it;
+    if (!df) cnt[9] += 1;
+}
+
 // LDS carve (in units of 8 bytes after the message area):
 //   [S]  next work index per slot
 //   [S]  MC logical-mask accumulator
-//   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count
-template <int DC, int DV, int VARIANT, bool MC, int MAX_THREADS>
-__global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams P)
+//   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
+//   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only)
+template <int DC, int DV, int VARIANT, bool MC, int MAX_THREADS, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kernel(const FusedParams P)
 {
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
@@ -126,6 +150,7 @@ __global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams
     int* const mc_weight = words + 2 * S;
     int* const mc_diff = words + 3 * S;
     int* const active_count = words + 4 * S;
+    int* const mc_count = words + 4 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
 
     // ---- per-lane static tables (registers for the whole kernel) ---------------------------
     int var[DC];
@@ -158,6 +183,9 @@ __global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams
         mc_lmask[slot] = 0ull;
         mc_weight[slot] = 0;
         mc_diff[slot] = 0;
+        if constexpr (MC) {
+            for (int i = 0; i < NUM_COUNTERS; ++i) mc_count[i] = 0;
+        }
         next_work[slot] = total_slots + (long long)atomicAdd(P.work_counter, 1ull);
     }
     if (tid == 0) {
@@ -181,29 +209,26 @@ __global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams
         if constexpr (MC) {
             const unsigned long long trial = (unsigned long long)(P.trial_begin + b);
             ebits = 0;
-#pragma unroll
-            for (int j = 0; j < DC; ++j)
-                if (var[j] >= 0)
-                    ebits |= mc_error_bit(trial, var[j], P.draws, P.seed, P.threshold) << j;
+#pragma unroll 1
+            for (int j = 0; j < DC; ++j) {        // once per trial: keep it out of the registers
+                const int v = P.tab_var[j * m + c];
+                if (v >= 0) ebits |= mc_error_bit(trial, v, P.draws, P.seed, P.threshold) << j;
+            }
             sbit = __builtin_popcount(ebits) & 1u;       // syndrome = H e mod 2
         } else {
             sbit = P.syndromes[b * m + c] & 1u;
         }
     };
-    if (active) start_syndrome();
+    bool need_start = active;     // (re)initialise at the loop top, where Q / val / R are dead
     __syncthreads();
 
     // leader-only bookkeeping
     bool refill = false;
     bool mc_pending = false;
     int mc_pending_conv = 0, mc_pending_it = 0;
-    long long cnt_local[NUM_COUNTERS];
-    if constexpr (MC) {
-#pragma unroll
-        for (int i = 0; i < NUM_COUNTERS; ++i) cnt_local[i] = 0;
-    }
 
     for (unsigned phase = 0;; ++phase) {
+        if (need_start) { start_syndrome(); need_start = false; }
         // ================= check step =======================================================
         if (active) {
             if constexpr (VARIANT == 2) {
@@ -288,23 +313,8 @@ __global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams
             }
             if constexpr (MC) {
                 if (mc_pending) {
-                    // classification of the trial emitted in the previous phase
-                    // (paperResults_GPU.py:127-144, BP only)
-                    const unsigned long long lm = mc_lmask[slot];
-                    const int ew = mc_weight[slot];
-                    const int df = mc_diff[slot];
-                    mc_lmask[slot] = 0ull; mc_weight[slot] = 0; mc_diff[slot] = 0;
-                    const bool logical = lm != 0ull;
-                    cnt_local[0] += 1;
-                    if (mc_pending_conv && !logical && df) cnt_local[5] += 1;
-                    if (logical) {
-                        cnt_local[1] += 1;
-                        if (ew < P.half_distance) cnt_local[3] += 1; else cnt_local[4] += 1;
-                        if (!mc_pending_conv) cnt_local[8] += 1;
-                    }
-                    if (!mc_pending_conv) cnt_local[6] += 1;
-                    cnt_local[7] += mc_pending_it;
-                    if (!df) cnt_local[9] += 1;
+                    mc_classify(mc_lmask, mc_weight, mc_diff, mc_count, slot, mc_pending_conv,
+                                mc_pending_it, P.half_distance);
                     mc_pending = false;
                 }
             }
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams
                 b = next_work[slot];
                 if (c == 0) refill = true;
                 if (b < B) {
-                    start_syndrome();
+                    need_start = true;
                 } else {
                     active = false;
                     if (c == 0) atomicSub(active_count, 1);
@@ -387,27 +397,13 @@ __global__ __launch_bounds__(MAX_THREADS) void bp_fused_kernel(const FusedParams
         if (leader) {
             // the last emitted trial of this slot may still be pending (emitted after B2 of the
             // final phase; everybody passed B1 since, so the accumulators are complete)
-            if (mc_pending) {
-                const unsigned long long lm = mc_lmask[slot];
-                const int ew = mc_weight[slot];
-                const int df = mc_diff[slot];
-                const bool logical = lm != 0ull;
-                cnt_local[0] += 1;
-                if (mc_pending_conv && !logical && df) cnt_local[5] += 1;
-                if (logical) {
-                    cnt_local[1] += 1;
-                    if (ew < P.half_distance) cnt_local[3] += 1; else cnt_local[4] += 1;
-                    if (!mc_pending_conv) cnt_local[8] += 1;
-                }
-                if (!mc_pending_conv) cnt_local[6] += 1;
-                cnt_local[7] += mc_pending_it;
-                if (!df) cnt_local[9] += 1;
-            }
-#pragma unroll
+            if (mc_pending)
+                mc_classify(mc_lmask, mc_weight, mc_diff, mc_count, slot, mc_pending_conv,
+                            mc_pending_it, P.half_distance);
             for (int i = 0; i < NUM_COUNTERS; ++i)
-                if (cnt_local[i])
+                if (mc_count[i])
                     atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i),
-                              (unsigned long long)cnt_local[i]);
+                              (unsigned long long)mc_count[i]);
         }
     }
 }
