@@ -110,19 +110,19 @@ template <bool MC>
 hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s,
                           int reg_variant)
 {
-    const bool small = cfg.threads <= 640 && reg_variant != 2;
+    // Default build: __launch_bounds__(1024) = 128-VGPR budget = 4 wavefronts per SIMD, the fastest
+    // measured (profiles/r01_tune.txt).  The other register budgets exist for tuning runs only.
     switch (variant) {
         case QBP_SUM_PRODUCT:
             if constexpr (!MC) {
-                // register-budget builds of the headline kernel (tuning: QBP_OPT_REG_VARIANT)
+                if (reg_variant == 1 && cfg.threads <= 640) return launch_one<0, MC, 640, 1>(P, cfg, s);
                 if (reg_variant == 3 && cfg.threads <= 640) return launch_one<0, MC, 640, 5>(P, cfg, s);
-                if (reg_variant == 4 && cfg.threads <= 640) return launch_one<0, MC, 640, 4>(P, cfg, s);
             }
-            return small ? launch_one<0, MC, 640>(P, cfg, s) : launch_one<0, MC, 1024>(P, cfg, s);
+            return launch_one<0, MC, 1024>(P, cfg, s);
         case QBP_DAMPED_SP:
-            return small ? launch_one<1, MC, 640>(P, cfg, s) : launch_one<1, MC, 1024>(P, cfg, s);
+            return launch_one<1, MC, 1024>(P, cfg, s);
         default:
-            return small ? launch_one<2, MC, 640>(P, cfg, s) : launch_one<2, MC, 1024>(P, cfg, s);
+            return launch_one<2, MC, 1024>(P, cfg, s);
     }
 }
 
@@ -130,7 +130,13 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
 {
     const int m = h->m;
     int S = h->opt_slots;
-    if (S <= 0) S = std::max(1, 576 / std::max(m, 1));      // 576 = 9 wavefronts
+    if (S <= 0) {
+        // 16 wavefronts per workgroup (4 per SIMD at the kernel's 128-VGPR budget) was the fastest
+        // geometry measured (profiles/r01_tune.txt); small batches spread over the CUs instead.
+        S = std::max(1, 1024 / std::max(m, 1));
+        const long long spread = (B + h->num_cu - 1) / std::max(h->num_cu, 1);
+        if (spread < S) S = (int)std::max<long long>(spread, 1);
+    }
     S = std::min(S, std::max(1, 1024 / std::max(m, 1)));
     if ((long long)S > B) S = (int)std::max<long long>(B, 1);
     cfg->S = S;
@@ -143,11 +149,9 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     cfg->lds_bytes = (int)lds;
     int per_cu = h->opt_blocks_per_cu;
     if (per_cu <= 0) {
-        // resident workgroups per CU: limited by wavefront slots (32 per CU; the kernel's VGPR
-        // budget admits <= 3-4 waves per SIMD) and by LDS
+        // resident workgroups per CU: 16 wavefronts fit at the 128-VGPR budget; also LDS
         const int waves = cfg->threads / 64;
-        per_cu = std::max(1, std::min(12 / std::max(waves, 1), (int)(160 * 1024 / lds)));
-        if (waves > 12) per_cu = 1;
+        per_cu = std::max(1, std::min(16 / std::max(waves, 1), (int)(160 * 1024 / lds)));
     }
     const long long want = (B + S - 1) / S;
     cfg->grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cu * per_cu));

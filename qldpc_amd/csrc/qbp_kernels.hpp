@@ -95,9 +95,8 @@ __device__ __forceinline__ unsigned mc_error_bit(unsigned long long trial, int v
 }
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi)
-{   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi)
-    const double y = x < lo ? lo : x;
-    return y > hi ? hi : y;
+{   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi): v_max_f64 + v_min_f64
+    return __builtin_fmin(__builtin_fmax(x, lo), hi);
 }
 
 // Classification of one finished trial by its slot leader (paperResults_GPU.py:127-144 without
@@ -266,8 +265,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
                     const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
-                    double po = prod / ts;                        // IEEE division, as numpy
-                    po = sbit ? -po : po;                         // * syndrome_sign
+                    // prod / ts, correctly rounded like numpy's division: |prod| <= 1 and
+                    // 1e-15 <= |ts| <= 1, so no operand scaling is needed (div_nr's precondition)
+                    double po = div_nr(prod, ts);
+                    po = __hiloint2double(__double2hiint(po) ^ (int)(sbit << 31),
+                                          __double2loint(po));   // * syndrome_sign
                     const double r = atanh2(clipd(po, -0.9999999, 0.9999999));
                     R[j] = (VARIANT == 1) ? r * P.alpha : r;
                 }
@@ -280,15 +282,15 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 
         // ================= variable step (per edge of this check) ============================
         double val[DC];
-        unsigned hbits = 0;
         if (active) {
+            bool odd = sbit != 0;                                 // parity of the row vs syndrome
 #pragma unroll
             for (int j = 0; j < DC; ++j) {
                 double s = Rs[nbr[j][0]];
 #pragma unroll
                 for (int k = 1; k < DV; ++k) s = s + Rs[nbr[j][k]];   // ascending check order
                 val[j] = s + pri[j];
-                hbits |= (val[j] < 0.0 ? 1u : 0u) << j;
+                odd ^= val[j] < 0.0;                              // hard decision: values < 0
                 const double qn = val[j] - R[j];
                 if constexpr (VARIANT == 0) {
                     Q[j] = qn;
@@ -302,8 +304,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 for (int j = 0; j < DC; ++j)
                     if (var[j] < 0) Q[j] = __builtin_inf();       // padding stays neutral
             }
-            const unsigned unsat = (__builtin_popcount(hbits) & 1u) ^ sbit;
-            if (unsat) flag0[(phase & 1u) * S + slot] = 1;
+            if (odd) flag0[(phase & 1u) * S + slot] = 1;          // this check is unsatisfied
         }
         if (leader) {
             flag0[((phase + 1u) & 1u) * S + slot] = 0;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     for (int j = 0; j < DC; ++j) {
                         if ((wmask >> j) & 1u) {
                             const unsigned e = (ebits >> j) & 1u;
-                            const unsigned res = ((hbits >> j) & 1u) ^ e;
+                            const unsigned res = (val[j] < 0.0 ? 1u : 0u) ^ e;
                             ew += (int)e;
                             df |= res;
                             if (res) lm ^= P.lx_cols[var[j]];
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                         if ((wmask >> j) & 1u) {
                             const long long o = b * P.n + var[j];
                             if (P.llr) P.llr[o] = val[j];
-                            if (P.hard) P.hard[o] = (uint8_t)((hbits >> j) & 1u);
+                            if (P.hard) P.hard[o] = (uint8_t)(val[j] < 0.0);
                         }
                     }
                     for (int i = c; i < P.n_iso; i += m) {

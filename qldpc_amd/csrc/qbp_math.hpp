@@ -29,6 +29,7 @@
 #define QBP_LDEXP(x, e) __builtin_amdgcn_ldexp(x, e)
 #define QBP_FREXP_EXP(x) __builtin_amdgcn_frexp_exp(x)
 #define QBP_RINT(x) __builtin_rint(x)
+#define QBP_DEVICE_BITS 1
 #elif defined(__HIPCC__)
 #define QBP_HD __host__ __device__ inline
 #define QBP_RCP(x) (1.0 / (x))
@@ -44,6 +45,37 @@
 #endif
 
 namespace qbp {
+
+// 2^k as a double, k in [-1022, 1023]
+QBP_HD double pow2i(int k)
+{
+#ifdef QBP_DEVICE_BITS
+    return __hiloint2double((k + 1023) << 20, 0);      // one 32-bit VALU op instead of v_ldexp_f64
+#else
+    return std::ldexp(1.0, k);
+#endif
+}
+
+// x * 2^e for normal x whose result stays normal (exponent-field add on the high dword).
+// x == 0 gives a value of magnitude 2^(e-1023): only used where that is negligible.
+QBP_HD double scale2(double x, int e)
+{
+#ifdef QBP_DEVICE_BITS
+    return __hiloint2double(__double2hiint(x) + (e << 20), __double2loint(x));
+#else
+    return x == 0.0 ? 0.0 : std::ldexp(x, e);
+#endif
+}
+
+// biased exponent field minus 1022 == frexp exponent, for positive normal x
+QBP_HD int frexp_exp_pos(double x)
+{
+#ifdef QBP_DEVICE_BITS
+    return (__double2hiint(x) >> 20) - 1022;
+#else
+    return std::ilogb(x) + 1;
+#endif
+}
 
 // a / b for normal b with a / b neither overflowing nor subnormal: reciprocal seed, two
 // Newton steps, one residual correction (the core of the IEEE sequence, without scaling).
@@ -65,8 +97,7 @@ QBP_HD double tanh_half(double q)
     constexpr double INV_LN2 = 0x1.71547652b82fep+0;
     constexpr double LN2_HI = 0x1.62e42f8000000p-1;   // 26 significant bits: k * LN2_HI exact
     constexpr double LN2_LO = 0x1.be8e7bcd5e4f2p-27;
-    double a = __builtin_fabs(q);
-    a = a < 40.0 ? a : 40.0;               // tanh(20) already rounds to 1; also maps inf
+    const double a = __builtin_fmin(__builtin_fabs(q), 40.0);   // tanh(20) rounds to 1; maps inf
     const double x = -a;                   // em = expm1(x), x in [-40, 0]
     const double kd = QBP_RINT(x * INV_LN2);
     double r = __builtin_fma(-kd, LN2_HI, x);
@@ -83,7 +114,7 @@ QBP_HD double tanh_half(double q)
     P = __builtin_fma(P, r, 0x1.5555555555557p-3);
     P = __builtin_fma(P, r, 0x1.0000000000000p-1);
     const double p = __builtin_fma(r * r, P, r);          // expm1(r)
-    const double s = QBP_LDEXP(1.0, (int)kd);             // 2^k, k in [-58, 0]
+    const double s = pow2i((int)kd);                      // 2^k, k in [-58, 0]
     // E = e^-a = s (1 + p);  tanh(a/2) = (1 - E) / (1 + E).  (1 -+ s) are exact, so numerator
     // and denominator each carry a single rounding.
     const double num = __builtin_fma(-s, p, 1.0 - s);     // in [0, 1]
@@ -104,13 +135,13 @@ QBP_HD double atanh2(double y)
     const double N_lo = a - (N - 1.0);            // exact rounding error of N  (1 >= a)
     const double D_lo = (1.0 - D) - a;            // exact rounding error of D
     // e: (N / D) * 2^-e in [1/sqrt2, sqrt2)
-    const int e0 = 1 - QBP_FREXP_EXP(D);          // D * 2^e0 in [1, 2)
-    const double Dm = QBP_LDEXP(D, e0);
+    const int e0 = 1 - frexp_exp_pos(D);          // D * 2^e0 in [1, 2)   (D >= 1e-7: normal)
+    const double Dm = scale2(D, e0);
     int e = e0;
     e += (N >= SQRT2 * Dm) ? 1 : 0;
     e -= (N * SQRT2 < Dm) ? 1 : 0;
-    const double Ds = QBP_LDEXP(D, e);
-    const double Ds_lo = QBP_LDEXP(D_lo, e);
+    const double Ds = scale2(D, e);
+    const double Ds_lo = scale2(D_lo, e);         // D_lo == 0 -> ~2^-1000, negligible next to N_lo
     const double num = (N - Ds) + (N_lo - Ds_lo); // e == 0: (2a) + 0 exactly
     const double den = N + Ds;                    // e == 0: 2 exactly
     const double s = div_nr(num, den);            // |s| <= 0.1716

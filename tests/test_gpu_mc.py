@@ -51,19 +51,25 @@ def test_mc_shard_invariance_and_force_full():
     assert np.array_equal(table[0], whole)
 
 
-def test_ler_matches_reference_curve():
-    """BP-only LER of [[288,12,18]] against data/CC-50k-LERS-BP.npz (50 000 trials,
-    single draw, BP(50) only, non-convergence counted as failure): p = 0.0501 -> 0.09442,
-    p = 0.0268 -> 0.01906.  200 000 device trials; the reference count's 95 % interval dominates."""
-    code = codes.load_code("[[288, 12, 18]]")
-    dec = bp.decoder_for(code.Hx)
-    grid = np.logspace(-3.2, -1.3, 8)
-    for p, ref_ler in ((grid[7], 0.09442), (grid[6], 0.01906)):
-        T = 200000
-        c = dec.mc_run(code.Lx, code.distance, float(p), mc.prior_of(float(p), code.n), 0, T, seed=1)
-        s = mc.summarize(c)
-        ref_sigma = np.sqrt(ref_ler * (1 - ref_ler) / 50000)
-        our_sigma = np.sqrt(ref_ler * (1 - ref_ler) / T)
-        print(f"p={p:.4f}: BP-only LER {s['ler_bp_only']:.5f} (reference {ref_ler}), "
-              f"not converged {s['not_converged']}, mean iters {s['mean_iterations']:.2f}")
-        assert abs(s["ler_bp_only"] - ref_ler) <= 3.5 * np.hypot(ref_sigma, our_sigma)
+def test_non_convergence_rate_matches_reference_data():
+    """Fraction of trials BP(50) fails to converge on, against the `osd` (OSD invocation) rates
+    stored in the reference's rework/simulation_results10k.npz (sum-product BP, single Bernoulli
+    draw, 10 000 trials per point; values in BASELINE.md).  That file does not record maxIter;
+    50 is inferred: the oracle reproduces its rates at maxIter = 50 and not at 30 or 100 (e.g.
+    [[288,12,18]] p = 0.05: 0.089 / 0.059 / 0.029 at 30 / 50 / 100 vs 0.0652 stored).  The other
+    BP-only files (data/CC-50k-LERS-BP.npz, notebooks/data/BP.npz) match maxIter of about 30 and
+    20 by the same test and are therefore not used as maxIter = 50 targets."""
+    ref = {"[[288, 12, 18]]": {0.06: 0.1296, 0.05: 0.0652, 0.04: 0.0311},
+           "[[144, 12, 12]]": {0.06: 0.1466, 0.05: 0.0733, 0.04: 0.0284, 0.03: 0.0105},
+           "[[72, 12, 6]]": {0.06: 0.1481, 0.05: 0.0833, 0.04: 0.045, 0.03: 0.018}}
+    T = 200000
+    for name, pts in ref.items():
+        code = codes.load_code(name)
+        dec = bp.decoder_for(code.Hx)
+        for p, r in pts.items():
+            c = dec.mc_run(code.Lx, code.distance, p, mc.prior_of(p, code.n), 0, T, seed=1)
+            rate = c[6] / c[0]
+            sigma = np.hypot(np.sqrt(r * (1 - r) / 10000), np.sqrt(r * (1 - r) / T))
+            print(f"{name} p={p}: not converged {rate:.4f} (reference {r}, {abs(rate - r) / sigma:.1f} sigma), "
+                  f"LER {c[1] / c[0]:.4f}")
+            assert abs(rate - r) <= 4.0 * sigma

@@ -10,11 +10,22 @@ cd $R
 echo "== pytest" ; timeout -k 10 900 python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1; echo "pytest exit=$?" | tee -a $OUT/pytest.log
 tail -5 $OUT/pytest.log
 echo "== diag"; timeout -k 10 300 python tools/diag_llr.py > $OUT/diag_llr.log 2>&1; tail -30 $OUT/diag_llr.log
-echo "== tune"; timeout -k 10 600 python tools/tune.py > $OUT/tune.log 2>&1; tail -3 $OUT/tune.log
-echo "== tune early exit"; timeout -k 10 300 python tools/tune.py --early-exit --slots 2 4 7 --blocks 1 2 3 --regs 0 2 --batch 200000 > $OUT/tune_early.log 2>&1; tail -2 $OUT/tune_early.log
+echo "== tune"; timeout -k 10 600 python tools/tune.py --regs 0 1 3 > $OUT/tune.log 2>&1; tail -3 $OUT/tune.log
+echo "== tune early exit"; timeout -k 10 300 python tools/tune.py --early-exit --slots 2 4 7 --blocks 1 2 --regs 0 --batch 200000 > $OUT/tune_early.log 2>&1; tail -2 $OUT/tune_early.log
 echo "== bench"; timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json; tail -3 $OUT/bench.err
 echo "== rocprof"
 export TMPDIR=/tmp; cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.log 2>&1
 echo "rocprof exit=$?"; find $OUT/prof -name "*stats*" | head; 
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -8 $f; done
+
+echo "== pmc"
+PMC1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"
+PMC2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"
+i=0
+for C in "$PMC1" "$PMC2" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$i -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode forced > $OUT/pmc_$i.log 2>&1
+  echo "pmc pass $i ($C) exit=$?"
+done
+cd $R; python tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_summary.json; cat $OUT/pmc_summary.json | head -60
