@@ -178,7 +178,7 @@ def main():
                        "lds_bytes": dec.info("lds_bytes")},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "qbp::bp_fused_kernel<6,3,0,false,1024,1>",
+                         "kernel": "qbp::bp_fused_kernel<6,3,0,false,true,1024,1>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "effective bandwidth: messages stay in LDS/registers, physical HBM "
                                  "traffic is only syndrome/LLR I/O; the physical limiter is FP64 VALU"},

@@ -95,15 +95,22 @@ struct LaunchCfg {
     int S, threads, lds_bytes, grid, slot_stride;
 };
 
-template <int VARIANT, bool MC, int MAXT, int MINW = 1>
-hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
+template <int VARIANT, bool MC, bool FORCE, int MAXT, int MINW>
+hipError_t launch_k(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
 {
-    auto kern = qbp::bp_fused_kernel<DC_FUSED, DV_FUSED, VARIANT, MC, MAXT, MINW>;
+    auto kern = qbp::bp_fused_kernel<DC_FUSED, DV_FUSED, VARIANT, MC, FORCE, MAXT, MINW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(cfg.threads), cfg.lds_bytes, stream, P);
     return hipGetLastError();
+}
+
+template <int VARIANT, bool MC, int MAXT, int MINW = 1>
+hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
+{
+    return (P.flags & QBP_FLAG_FORCE_FULL) ? launch_k<VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
+                                           : launch_k<VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
 }
 
 template <bool MC>

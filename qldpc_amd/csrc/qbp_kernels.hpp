@@ -127,7 +127,7 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
 //   [S]  MC logical-mask accumulator
 //   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
 //   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only)
-template <int DC, int DV, int VARIANT, bool MC, int MAX_THREADS, int MIN_WAVES_PER_SIMD>
+template <int DC, int DV, int VARIANT, bool MC, bool FORCE_FULL, int MAX_THREADS, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kernel(const FusedParams P)
 {
     extern __shared__ double smem[];
@@ -168,10 +168,15 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 
     const long long B = P.B;
     const long long total_slots = (long long)gridDim.x * S;
-    const bool force_full = (P.flags & 1u) != 0;
     const double one_minus_damping = 1.0 - P.damping;
     const int max_iter = P.max_iter;
 
+    // Work distribution: the first syndrome of a slot is static; afterwards the slot leader draws
+    // chunks of WORK_CHUNK consecutive indices from one global counter (one returning atomic per
+    // WORK_CHUNK syndromes: a single word sustains only ~88 dequeues/us, MI355X_MICROARCH.md
+    // 'dequeue', which early-exit decoding at low error rates would exceed).
+    constexpr int WORK_CHUNK = 8;
+    long long chunk_end = 0;      // leader only: end of the chunk next_work[slot] points into
     long long b = lane_valid ? (long long)blockIdx.x * S + slot : B;
     bool active = b < B;
 
@@ -185,7 +190,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         if constexpr (MC) {
             for (int i = 0; i < NUM_COUNTERS; ++i) mc_count[i] = 0;
         }
-        next_work[slot] = total_slots + (long long)atomicAdd(P.work_counter, 1ull);
+        chunk_end = total_slots + (long long)atomicAdd(P.work_counter, (unsigned long long)WORK_CHUNK);
+        next_work[slot] = chunk_end;
+        chunk_end += WORK_CHUNK;
     }
     if (tid == 0) {
         long long first = (long long)blockIdx.x * S;
@@ -309,7 +316,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         if (leader) {
             flag0[((phase + 1u) & 1u) * S + slot] = 0;
             if (refill) {
-                next_work[slot] = total_slots + (long long)atomicAdd(P.work_counter, 1ull);
+                long long nx = next_work[slot] + 1;
+                if (nx == chunk_end) {
+                    nx = total_slots +
+                         (long long)atomicAdd(P.work_counter, (unsigned long long)WORK_CHUNK);
+                    chunk_end = nx + WORK_CHUNK;
+                }
+                next_work[slot] = nx;
                 refill = false;
             }
             if constexpr (MC) {
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 }
             }
             if (conv) frozen = true;
-            const bool finished = last || (conv && !force_full);
+            const bool finished = last || (conv && !FORCE_FULL);
             if (finished) {
                 b = next_work[slot];
                 if (c == 0) refill = true;
