@@ -48,9 +48,12 @@ enum {
 
 /* flags */
 enum {
-    QBP_FLAG_FORCE_FULL = 1u /* run all max_iter iterations for every syndrome; outputs are still
-                                those of the first converged iteration (bench mode "M2") */
+    QBP_FLAG_FORCE_FULL = 1u, /* run all max_iter iterations for every syndrome; outputs are still
+                                 those of the first converged iteration (bench mode "M2") */
+    QBP_FLAG_OSD0 = 2u        /* qbp_mc_run only: trials BP does not converge on go through OSD-0
+                                 (decoding/OSD.py) before classification, as paperResults.py:73-77 */
 };
+#define QBP_MC_OSD_MAX_TRIALS (1 << 20) /* per qbp_mc_run call with QBP_FLAG_OSD0 (record buffers) */
 
 /*
  * Build a decoder for the parity-check matrix H given in CSR form.
@@ -99,7 +102,8 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
  *   [0] trials  [1] logical_error  [2] BPs_fault (always 0, as in the reference)
  *   [3] BPs_miscorrected  [4] incorrectable  [5] degenerateErrors          (:80-84, :133-144)
  *   [6] not_converged (= trials the reference would hand to OSD)  [7] sum of iteration indices
- *   [8] logical_error among not_converged  [9] hard == error exactly  [10], [11] reserved (0).
+ *   [8] logical_error among not_converged  [9] detection == error exactly
+ *   [10] OSD outputs that miss the syndrome (always 0)  [11] reserved (0).
  */
 #define QBP_NUM_COUNTERS 12
 int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, double p,
@@ -114,6 +118,17 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
                       int64_t trial_end, const double* d_prior, int32_t max_iter,
                       int32_t variant, double alpha, double damping, double clip_llr,
                       uint32_t flags, int64_t* d_counters, void* stream);
+
+/*
+ * OSD-0 post-processing of B decoder outputs: decoding/OSD.py:3-28 performOSD (= OSD_enhanced.py
+ * with order 0).  syndromes [B][m], llr [B][n], hard [B][n] -> solution [B][n].  Columns are
+ * ordered by ascending |llr|; equal values by ascending column index (np.argsort's order of
+ * equal keys is unspecified in the reference).
+ */
+int qbp_osd0_batch(qbp_handle* h, const uint8_t* syndromes, const double* llr, const uint8_t* hard,
+                   int64_t B, uint8_t* solution);
+int qbp_osd0_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const double* d_llr,
+                          const uint8_t* d_hard, int64_t B, uint8_t* d_solution, void* stream);
 
 /* Errors the sampler of qbp_mc_run draws for trials [trial_begin, trial_begin + T):
  * errors [T][n] host bytes.  For tests (compared bit for bit with the oracle's restatement). */

@@ -47,6 +47,8 @@ def lib():
         L.oracle_mc_errors.restype = None
         L.oracle_mc_errors.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                        C.c_int64, C.c_void_p]
+        L.oracle_osd0.restype = C.c_int
+        L.oracle_osd0.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 5
         L.oracle_mc_threshold.restype = C.c_uint32
         L.oracle_mc_threshold.argtypes = [C.c_double]
         _LIB = L
@@ -103,7 +105,7 @@ def sample_errors_and_syndromes(H, error_rate, batch_size, rng):
 
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
                  "degenerateErrors", "not_converged", "sum_iterations",
-                 "logical_error_not_converged", "exact_recoveries", "reserved0", "reserved1")
+                 "logical_error_not_converged", "exact_recoveries", "osd_invalid", "reserved1")
 
 
 def classify_trials(H, Lx, distance, errors, syndromes, detections, converged, iters):
@@ -135,11 +137,35 @@ def classify_trials(H, Lx, distance, errors, syndromes, detections, converged, i
 
 
 def mc_counters(H, Lx, distance, p, prior, trial_begin, trial_end, draws=1, seed=0, max_iter=50,
-                variant=0, alpha=1.0, damping=1.0, clip_llr=20.0):
-    """CPU statement of qbp_mc_run: Philox errors -> syndromes -> oracle decode -> classification."""
+                variant=0, alpha=1.0, damping=1.0, clip_llr=20.0, osd=False):
+    """CPU statement of qbp_mc_run: Philox errors -> syndromes -> oracle decode [-> OSD-0 on the
+    non-converged trials, paperResults.py:73-77] -> classification."""
     H = np.asarray(H).astype(np.int64)
     errors = mc_errors(H.shape[1], p, draws, seed, trial_begin, trial_end - trial_begin)
     syndromes = (errors.astype(np.int64) @ H.T % 2).astype(np.uint8)
-    hard, conv, iters, _ = decode_batch(H, syndromes, prior, max_iter, variant, alpha, damping,
-                                        clip_llr)
-    return classify_trials(H, Lx, distance, errors, syndromes, hard, conv, iters)
+    hard, conv, iters, llr = decode_batch(H, syndromes, prior, max_iter, variant, alpha, damping,
+                                          clip_llr)
+    if osd:
+        hard = hard.copy()
+        for i in np.flatnonzero(~conv):
+            hard[i] = osd0(H, syndromes[i], llr[i], hard[i])
+    cnt = classify_trials(H, Lx, distance, errors, syndromes, hard, conv, iters)
+    if osd:     # invalid OSD outputs (never happens: the residual syndrome is in the column space)
+        cnt[10] = sum(not np.array_equal((hard[i].astype(np.int64) @ H.T) % 2, syndromes[i])
+                      for i in np.flatnonzero(~conv))
+    return cnt
+
+
+def osd0(H, syndrome, llr, hard):
+    """decoding/OSD.py:3-28 performOSD (ties in |llr| broken by column index; see bp_oracle.c)."""
+    Hb = np.ascontiguousarray(np.asarray(H) != 0, np.uint8)
+    m, n = Hb.shape
+    syn = np.ascontiguousarray(np.asarray(syndrome).astype(np.uint8) & 1)
+    l = np.ascontiguousarray(llr, np.float64)
+    h = np.ascontiguousarray(np.asarray(hard).astype(np.uint8) & 1)
+    out = np.zeros(n, np.uint8)
+    rank = lib().oracle_osd0(m, n, Hb.ctypes.data, syn.ctypes.data, l.ctypes.data, h.ctypes.data,
+                             out.ctypes.data)
+    if rank < 0:
+        raise MemoryError
+    return out

@@ -15,10 +15,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libqbp.so")
 
 SUM_PRODUCT, DAMPED_SP, MIN_SUM = 0, 1, 2
 FLAG_FORCE_FULL = 1
+FLAG_OSD0 = 2
+MC_OSD_MAX_TRIALS = 1 << 20
 NUM_COUNTERS = 12
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
                  "degenerateErrors", "not_converged", "sum_iterations",
-                 "logical_error_not_converged", "exact_recoveries", "reserved0", "reserved1")
+                 "logical_error_not_converged", "exact_recoveries", "osd_invalid", "reserved1")
 OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_REG_VARIANT = 1, 2, 3
 INFO = dict(m=100, n=101, edges=102, max_row_deg=103, max_col_deg=104, kernel_kind=105,
             threads=106, lds_bytes=107, grid=108, num_cu=109)
@@ -41,6 +43,8 @@ SIGNATURES = {
                                     C.c_double, C.c_double, C.c_double, C.c_uint32, _VP, _VP]),
     "qbp_mc_sample_errors": (C.c_int, [_VP, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                        C.c_int64, _VP]),
+    "qbp_osd0_batch": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    "qbp_osd0_batch_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP]),
     "qbp_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
     "qbp_get_info": (C.c_int64, [_VP, C.c_int32]),
     "qbp_debug_math": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int64]),
@@ -158,6 +162,20 @@ class Decoder:
             self._h, Lx.ctypes.data, Lx.shape[0], int(distance), float(p), int(draws), int(seed),
             int(trial_begin), int(trial_end), d_prior, int(max_iter), int(variant), float(alpha),
             float(damping), float(clip_llr), int(flags), d_counters, stream or None))
+
+    def osd0(self, syndromes, llr, hard):
+        """OSD-0 on B decoder outputs (host arrays) -> solution uint8[B, n]."""
+        syn = np.ascontiguousarray(syndromes, np.uint8)
+        l = np.ascontiguousarray(llr, np.float64)
+        hd = np.ascontiguousarray(hard, np.uint8)
+        if syn.ndim != 2 or syn.shape[1] != self.m:
+            raise ValueError(f"syndromes must have shape (B, {self.m})")
+        if l.shape != (syn.shape[0], self.n) or hd.shape != l.shape:
+            raise ValueError(f"llr and hard must have shape ({syn.shape[0]}, {self.n})")
+        sol = np.empty_like(hd)
+        _check(load().qbp_osd0_batch(self._h, syn.ctypes.data, l.ctypes.data, hd.ctypes.data,
+                                     syn.shape[0], sol.ctypes.data))
+        return sol
 
     def mc_sample_errors(self, p, trial_begin, T, draws=1, seed=0):
         out = np.empty((int(T), self.n), np.uint8)

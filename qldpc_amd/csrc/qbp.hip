@@ -12,6 +12,7 @@
 
 #include "../../include/qbp.h"
 #include "qbp_kernels.hpp"
+#include "qbp_osd.hpp"
 
 static_assert(QBP_NUM_COUNTERS == qbp::NUM_COUNTERS, "counter layout");
 
@@ -85,6 +86,17 @@ struct qbp_handle {
     DevBuf<long long> d_counters;
     std::vector<uint8_t> lx_cache;   // last uploaded Lx (host copy) to skip re-uploads
     int lx_cache_k = -1;
+    // OSD-0
+    bool osd_ok = false;
+    int osd_W = 0, osd_NP = 0, osd_lds = 0;
+    DevBuf<uint32_t> d_hbits;
+    DevBuf<int32_t> d_row_ptr, d_col_idx;
+    DevBuf<uint8_t> d_sol;
+    // Monte-Carlo + OSD failure records
+    DevBuf<long long> d_fail_list;
+    DevBuf<unsigned long long> d_fail_count;
+    DevBuf<uint8_t> d_fail_syn, d_fail_hard, d_fail_err;
+    DevBuf<double> d_fail_llr;
 };
 
 namespace {
@@ -285,7 +297,25 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
         up(h->d_tab_writer, tab_writer);
     }
     up(h->d_iso, iso);
+    {   // OSD-0: bit-packed rows of H and its CSR
+        const int W = (n + 31) / 32;
+        int NP = 1;
+        while (NP < n) NP <<= 1;
+        const size_t lds = (size_t)NP * 12 + (size_t)m * (W + 1) * 4 + (size_t)m * 4 + (size_t)n + 16;
+        h->osd_W = W; h->osd_NP = NP; h->osd_lds = (int)((lds + 15) & ~(size_t)15);
+        h->osd_ok = lds <= 64 * 1024;
+        if (h->osd_ok) {
+            std::vector<uint32_t> hbits((size_t)m * W, 0u);
+            for (int c = 0; c < m; ++c)
+                for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e)
+                    hbits[(size_t)c * W + (col_idx[e] >> 5)] |= 1u << (col_idx[e] & 31);
+            up(h->d_hbits, hbits);
+            up(h->d_row_ptr, h->row_ptr);
+            up(h->d_col_idx, h->col_idx);
+        }
+    }
     if (e1 == hipSuccess) e1 = h->d_work_counter.reserve(1);
+    if (e1 == hipSuccess) e1 = h->d_fail_count.reserve(1);
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e1 != hipSuccess) {
         int rc = fail(QBP_E_HIP, "device setup failed: %s", hipGetErrorString(e1));
@@ -305,6 +335,9 @@ void qbp_destroy(qbp_handle* h)
     h->d_work_counter.release(); h->d_syn.release(); h->d_hard.release(); h->d_conv.release();
     h->d_lx_bytes.release(); h->d_iters.release(); h->d_llr.release(); h->d_prior.release();
     h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
+    h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
+    h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
+    h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
     delete h;
 }
 
@@ -396,6 +429,55 @@ static unsigned mc_threshold(double p)
     return (unsigned)t;
 }
 
+static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hipStream_t s)
+{
+    if (!h->osd_ok)
+        return fail(QBP_E_UNSUPPORTED, "OSD-0 needs %d B of LDS for this H (limit 64 KiB)", h->osd_lds);
+    O.m = h->m; O.n = h->n; O.W = h->osd_W; O.NP = h->osd_NP;
+    O.hbits = h->d_hbits.p; O.row_ptr = h->d_row_ptr.p; O.col_idx = h->d_col_idx.p;
+    const long long grid = std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 32));
+    hipLaunchKernelGGL(qbp::osd0_kernel, dim3((unsigned)grid), dim3(64), h->osd_lds, s, O);
+    HIP_TRY(hipGetLastError());
+    return QBP_OK;
+}
+
+int qbp_osd0_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const double* d_llr,
+                          const uint8_t* d_hard, int64_t B, uint8_t* d_solution, void* stream)
+{
+    if (!h) return fail(QBP_E_INVALID, "null handle");
+    if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0");
+    if (B == 0) return QBP_OK;
+    if (!d_syndromes || !d_llr || !d_hard || !d_solution) return fail(QBP_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    qbp::OsdParams O{};
+    O.count = B; O.syndromes = d_syndromes; O.llr = d_llr; O.hard = d_hard; O.solution = d_solution;
+    return osd_launch(h, O, B, static_cast<hipStream_t>(stream));
+}
+
+int qbp_osd0_batch(qbp_handle* h, const uint8_t* syndromes, const double* llr, const uint8_t* hard,
+                   int64_t B, uint8_t* solution)
+{
+    if (!h) return fail(QBP_E_INVALID, "null handle");
+    if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0");
+    if (B == 0) return QBP_OK;
+    if (!syndromes || !llr || !hard || !solution) return fail(QBP_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t m = h->m, n = h->n, b = (size_t)B;
+    HIP_TRY(h->d_syn.reserve(b * m));
+    HIP_TRY(h->d_llr.reserve(b * n));
+    HIP_TRY(h->d_hard.reserve(b * n));
+    HIP_TRY(h->d_sol.reserve(b * n));
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->d_syn.p, syndromes, b * m, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_llr.p, llr, b * n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_hard.p, hard, b * n, hipMemcpyHostToDevice, s));
+    int rc = qbp_osd0_batch_device(h, h->d_syn.p, h->d_llr.p, h->d_hard.p, B, h->d_sol.p, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(solution, h->d_sol.p, b * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return QBP_OK;
+}
+
 int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t distance,
                       double p, int32_t draws, uint64_t seed, int64_t trial_begin,
                       int64_t trial_end, const double* d_prior, int32_t max_iter,
@@ -424,8 +506,37 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
     P.lx_cols = h->d_lx_cols.p; P.trial_begin = trial_begin; P.seed = seed;
     P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = distance / 2;
     P.counters = reinterpret_cast<long long*>(d_counters);
+    const bool osd = (flags & QBP_FLAG_OSD0) != 0;
+    if (osd) {
+        if (!h->osd_ok) return fail(QBP_E_UNSUPPORTED, "OSD-0 not available for this H");
+        if (T > QBP_MC_OSD_MAX_TRIALS)
+            return fail(QBP_E_INVALID, "with QBP_FLAG_OSD0 a call covers at most %d trials (got %lld); "
+                                       "split the range", QBP_MC_OSD_MAX_TRIALS, (long long)T);
+        const size_t t = (size_t)T, m = h->m, n = h->n;
+        HIP_TRY(h->d_fail_list.reserve(t));
+        HIP_TRY(h->d_fail_syn.reserve(t * m));
+        HIP_TRY(h->d_fail_llr.reserve(t * n));
+        HIP_TRY(h->d_fail_hard.reserve(t * n));
+        HIP_TRY(h->d_fail_err.reserve(t * n));
+        HIP_TRY(hipMemsetAsync(h->d_fail_count.p, 0, sizeof(unsigned long long), s));
+        P.fail_list = h->d_fail_list.p; P.fail_count = h->d_fail_count.p;
+        P.fail_syn = h->d_fail_syn.p; P.fail_llr = h->d_fail_llr.p;
+        P.fail_hard = h->d_fail_hard.p; P.fail_err = h->d_fail_err.p;
+    }
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
     HIP_TRY(launch_variant<true>(variant, P, cfg, s, h->opt_reg_variant));
+    if (osd) {
+        // second kernel: OSD-0 + classification of the trials BP left unconverged; their number is
+        // read from device memory by the kernel itself (no host round trip)
+        qbp::OsdParams O{};
+        O.count_ptr = reinterpret_cast<const long long*>(h->d_fail_count.p);
+        O.list = h->d_fail_list.p;
+        O.syndromes = h->d_fail_syn.p; O.llr = h->d_fail_llr.p; O.hard = h->d_fail_hard.p;
+        O.errors = h->d_fail_err.p; O.lx_cols = h->d_lx_cols.p; O.half_distance = distance / 2;
+        O.counters = reinterpret_cast<long long*>(d_counters);
+        rc = osd_launch(h, O, T, s);
+        if (rc) return rc;
+    }
     return QBP_OK;
 }
 

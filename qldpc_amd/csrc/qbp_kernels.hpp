@@ -66,6 +66,14 @@ struct FusedParams {
     int half_distance;          // distance // 2
     long long* counters;        // [NUM_COUNTERS], atomically added
     uint8_t* errors_out;        // optional [B][n] dump of sampled errors (tests)
+    // Monte-Carlo + OSD: records of the trials BP did not converge on (indexed by the trial's
+    // position b in this launch), and the list of those positions
+    long long* fail_list;       // null = classify BP output directly
+    unsigned long long* fail_count;
+    uint8_t* fail_syn;          // [B][m]
+    double* fail_llr;           // [B][n]
+    uint8_t* fail_hard;         // [B][n]
+    uint8_t* fail_err;          // [B][n]
 };
 
 __device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1)
@@ -103,8 +111,12 @@ __device__ __forceinline__ double clipd(double x, double lo, double hi)
 // the OSD call): reads and clears the slot's accumulators, bumps the slot's counter row in LDS.
 __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* mc_weight,
                                             int* mc_diff, int* cnt, int slot, int conv, int it,
-                                            int half_distance)
+                                            int half_distance, bool deferred)
 {
+    if (deferred) {            // handed to OSD: only the BP bookkeeping is counted here
+        cnt[0] += 1; cnt[6] += 1; cnt[7] += it;
+        return;
+    }
     const unsigned long long lm = mc_lmask[slot];
     const int ew = mc_weight[slot];
     const int df = mc_diff[slot];
@@ -328,7 +340,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             if constexpr (MC) {
                 if (mc_pending) {
                     mc_classify(mc_lmask, mc_weight, mc_diff, mc_count, slot, mc_pending_conv,
-                                mc_pending_it, P.half_distance);
+                                mc_pending_it, P.half_distance,
+                                P.fail_list != nullptr && !mc_pending_conv);
                     mc_pending = false;
                 }
             }
@@ -341,6 +354,28 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             const bool last = it == max_iter - 1;
             if (!frozen && (conv || last)) {
                 if constexpr (MC) {
+                    const unsigned long long trial = (unsigned long long)(P.trial_begin + b);
+                    if (P.fail_list != nullptr && !conv) {
+                        // BP failed: leave the trial to the OSD kernel (record indexed by b)
+                        P.fail_syn[b * m + c] = (uint8_t)sbit;
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) {
+                            if ((wmask >> j) & 1u) {
+                                const long long o = b * P.n + var[j];
+                                P.fail_llr[o] = val[j];
+                                P.fail_hard[o] = (uint8_t)(val[j] < 0.0);
+                                P.fail_err[o] = (uint8_t)((ebits >> j) & 1u);
+                            }
+                        }
+                        for (int i = c; i < P.n_iso; i += m) {
+                            const int v = P.iso_vars[i];
+                            const long long o = b * P.n + v;
+                            P.fail_llr[o] = P.prior[v];
+                            P.fail_hard[o] = (uint8_t)(P.prior[v] < 0.0);
+                            P.fail_err[o] = (uint8_t)mc_error_bit(trial, v, P.draws, P.seed, P.threshold);
+                        }
+                        if (c == 0) P.fail_list[atomicAdd(P.fail_count, 1ull)] = b;
+                    } else {
                     unsigned long long lm = 0ull;
                     int ew = 0;
                     unsigned df = 0;
@@ -357,8 +392,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     }
                     for (int i = c; i < P.n_iso; i += m) {
                         const int v = P.iso_vars[i];
-                        const unsigned e = mc_error_bit((unsigned long long)(P.trial_begin + b), v,
-                                                        P.draws, P.seed, P.threshold);
+                        const unsigned e = mc_error_bit(trial, v, P.draws, P.seed, P.threshold);
                         const unsigned res = (P.prior[v] < 0.0 ? 1u : 0u) ^ e;
                         ew += (int)e;
                         df |= res;
@@ -368,6 +402,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     if (lm) atomicXor(&mc_lmask[slot], lm);
                     if (ew) atomicAdd(&mc_weight[slot], ew);
                     if (df) atomicOr(&mc_diff[slot], 1);
+                    }
                     if (c == 0) { mc_pending = true; mc_pending_conv = conv; mc_pending_it = it; }
                 } else {
 #pragma unroll
@@ -413,7 +448,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             // final phase; everybody passed B1 since, so the accumulators are complete)
             if (mc_pending)
                 mc_classify(mc_lmask, mc_weight, mc_diff, mc_count, slot, mc_pending_conv,
-                            mc_pending_it, P.half_distance);
+                            mc_pending_it, P.half_distance,
+                            P.fail_list != nullptr && !mc_pending_conv);
             for (int i = 0; i < NUM_COUNTERS; ++i)
                 if (mc_count[i])
                     atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i),

@@ -1,0 +1,172 @@
+// OSD-0 post-processing on the GPU: decoding/OSD.py:3-72 (performOSD + gf2_elimination).
+//
+// One wavefront per syndrome.  The reference permutes the columns of H by ascending |LLR|, runs a
+// Gauss-Jordan elimination with row swaps and reads the solution off the pivot columns.  The
+// solution only depends on WHICH columns become pivots (the greedy, first-independent-columns
+// basis in reliability order) -- not on which row serves as the pivot -- so this kernel never
+// swaps or permutes: it keeps the bit-packed rows of H in LDS in their original column indexing,
+// walks the columns in sorted order, picks any not-yet-used row with a 1 in that column as the
+// pivot and XORs it into every other row that has the bit (rows are n bits + the syndrome bit).
+// Sorting: bitonic network over (|llr|, column index) pairs in LDS; ties in |llr| fall back to the
+// column index (the reference's np.argsort is unstable there; oracle/bp_oracle.c does the same).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qbp {
+
+struct OsdParams {
+    // code
+    int m, n, W;                    // W = 32-bit words per row of H ((n + 31) / 32)
+    int NP;                         // power of two >= n (sort width)
+    const uint32_t* hbits;          // [m][W] bit-packed rows of H
+    const int32_t* row_ptr;         // CSR of H
+    const int32_t* col_idx;
+    // batch: record index of syndrome i is list ? list[i] : i
+    long long count;
+    const long long* count_ptr;     // optional: number of records (device), overrides count
+    const long long* list;
+    const uint8_t* syndromes;       // [*][m]
+    const double* llr;              // [*][n]
+    const uint8_t* hard;            // [*][n]
+    uint8_t* solution;              // [*][n] (may be null in Monte-Carlo mode)
+    // Monte-Carlo classification (paperResults_GPU.py:127-144 on the OSD output)
+    const uint8_t* errors;          // [*][n] or null
+    const unsigned long long* lx_cols;
+    int half_distance;
+    long long* counters;
+};
+
+__device__ __forceinline__ bool osd_less(double ka, int ia, double kb, int ib)
+{
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+// LDS: double keys[NP]; int idx[NP]; uint32 A[m][W+1]; int pivcol[m]; uint8 sol[n]
+__global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
+{
+    extern __shared__ double osd_smem[];
+    const int lane = threadIdx.x;
+    const int m = P.m, n = P.n, W = P.W, NP = P.NP, RS = P.W + 1;
+    double* keys = osd_smem;
+    int* idx = reinterpret_cast<int*>(keys + NP);
+    uint32_t* A = reinterpret_cast<uint32_t*>(idx + NP);
+    int* pivcol = reinterpret_cast<int*>(A + (size_t)m * RS);
+    uint8_t* sol = reinterpret_cast<uint8_t*>(pivcol + m);
+
+    const long long total = P.count_ptr ? *P.count_ptr : P.count;
+    for (long long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long long rec = P.list ? P.list[item] : item;
+        const double* llr = P.llr + rec * n;
+        const uint8_t* hard = P.hard + rec * n;
+        const uint8_t* syn = P.syndromes + rec * m;
+
+        // ---- 1. ordering = argsort(|llr|)                                    OSD.py:10-11
+        for (int i = lane; i < NP; i += 64) {
+            keys[i] = i < n ? __builtin_fabs(llr[i]) : __builtin_inf();
+            idx[i] = i;
+        }
+        for (int i = lane; i < n; i += 64) sol[i] = hard[i] & 1u;
+        __syncthreads();
+        for (int k = 2; k <= NP; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < NP / 2; t += 64) {
+                    const int lo = ((t / j) * (2 * j)) + (t % j);   // element with bit j clear
+                    const int hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const double ka = keys[lo], kb = keys[hi];
+                    const int ia = idx[lo], ib = idx[hi];
+                    if (osd_less(kb, ib, ka, ia) == up) {
+                        keys[lo] = kb; keys[hi] = ka; idx[lo] = ib; idx[hi] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- 2. A = [H | residual syndrome], residual = syndrome + hard @ H.T  OSD.py:7-8
+        for (int r = lane; r < m; r += 64) {
+            for (int w = 0; w < W; ++w) A[r * RS + w] = P.hbits[r * W + w];
+            unsigned par = syn[r] & 1u;
+            for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) par ^= sol[P.col_idx[e]];
+            A[r * RS + W] = par;
+            pivcol[r] = -1;
+        }
+        __syncthreads();
+        // ---- 3. Gauss-Jordan over the columns in reliability order            OSD.py:31-72
+        int rank = 0;
+        for (int k = 0; k < n && rank < m; ++k) {
+            const int c = idx[k];
+            const int wi = c >> 5;
+            const uint32_t bit = 1u << (c & 31);
+            int p = -1;
+            for (int base = 0; base < m && p < 0; base += 64) {
+                const int r = base + lane;
+                const bool cand = r < m && pivcol[r] < 0 && (A[r * RS + wi] & bit);
+                const unsigned long long mask = __ballot(cand);
+                if (mask) p = base + (int)__builtin_ctzll(mask);
+            }
+            if (p < 0) continue;                     // column depends on earlier ones (:52-53)
+            ++rank;
+            for (int r = lane; r < m; r += 64) {
+                if (r != p && (A[r * RS + wi] & bit)) {
+                    for (int w = 0; w <= W; ++w) A[r * RS + w] ^= A[p * RS + w];   // :63-68
+                }
+            }
+            if (lane == 0) pivcol[p] = c;
+            __syncthreads();
+        }
+        // ---- 4. e[pivot column] = reduced syndrome bit; solution = hard + e    OSD.py:14-26
+        for (int r = lane; r < m; r += 64) {
+            const int c = pivcol[r];
+            if (c >= 0 && (A[r * RS + W] & 1u)) sol[c] ^= 1u;
+        }
+        __syncthreads();
+        if (P.solution)
+            for (int i = lane; i < n; i += 64) P.solution[rec * n + i] = sol[i];
+
+        if (P.errors) {
+            // classification of the OSD output (paperResults_GPU.py:127-144)
+            const uint8_t* err = P.errors + rec * n;
+            unsigned long long lm = 0ull;
+            int ew = 0;
+            unsigned df = 0;
+            for (int i = lane; i < n; i += 64) {
+                const unsigned e = err[i] & 1u;
+                const unsigned res = sol[i] ^ e;
+                ew += (int)e;
+                df |= res;
+                if (res) lm ^= P.lx_cols[i];
+            }
+            unsigned bad = 0;                        // is_valid_osd: (detection @ H.T) % 2 == syndrome
+            for (int r = lane; r < m; r += 64) {
+                unsigned par = syn[r] & 1u;
+                for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) par ^= sol[P.col_idx[e]];
+                bad |= par;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                lm ^= __shfl_xor(lm, off);
+                ew += __shfl_xor(ew, off);
+                df |= __shfl_xor(df, off);
+                bad |= __shfl_xor(bad, off);
+            }
+            if (lane == 0) {
+                auto add = [&](int i) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i), 1ull);
+                };
+                const bool logical = lm != 0ull;
+                if (!bad && !logical && df) add(5);
+                if (logical) {
+                    add(1);
+                    add(ew < P.half_distance ? 3 : 4);
+                    add(8);
+                }
+                if (!df) add(9);
+                if (bad) add(10);                    // OSD output that misses the syndrome (never)
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace qbp

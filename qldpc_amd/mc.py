@@ -39,7 +39,7 @@ def summarize(counters: np.ndarray) -> dict:
     """Counter row -> the per-point quantities the reference stores / prints."""
     c = {k: int(v) for k, v in zip(_lib.COUNTER_NAMES, counters)}
     t = max(c["trials"], 1)
-    c["ler"] = c["logical_error"] / t                                   # :146
+    c["ler"] = c["logical_error"] / t                                   # :146 (BP+OSD when osd)
     # BP-only convention of notebooks/data/BP.npz: a non-converged trial counts as a failure
     c["ler_bp_only"] = (c["logical_error"] - c["logical_error_not_converged"]
                         + c["not_converged"]) / t
@@ -48,8 +48,8 @@ def summarize(counters: np.ndarray) -> dict:
 
 
 def run_sweep(code_name, ps, trials, *, draws=1, seed=0, max_iter=50, variant=_lib.SUM_PRODUCT,
-              alpha=1.0, damping=1.0, clip_llr=20.0, rank=0, world=1, device=0, runner=None,
-              all_reduce=None):
+              alpha=1.0, damping=1.0, clip_llr=20.0, osd=False, rank=0, world=1, device=0,
+              runner=None, all_reduce=None):
     """Returns the GLOBAL counter table int64[len(ps), 12] (after the reduce).
 
     `runner(code, p, begin, end) -> int64[12]` and `all_reduce(int64 array) -> int64 array`
@@ -65,12 +65,16 @@ def run_sweep(code_name, ps, trials, *, draws=1, seed=0, max_iter=50, variant=_l
         d_table = torch.zeros((len(ps), NUM_COUNTERS), dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream(dev)
         priors = [torch.from_numpy(prior_of(p, code.n)).to(dev) for p in ps]
+        flags = _lib.FLAG_OSD0 if osd else 0
+        step = _lib.MC_OSD_MAX_TRIALS if osd else 1 << 40    # OSD keeps per-trial records
         for i, p in enumerate(ps):
             begin, end = shard_range(trials, rank, world)
-            dec.mc_run_device(code.Lx, code.distance, p, priors[i].data_ptr(), begin, end,
-                              d_table[i].data_ptr(), draws=draws, seed=seed, max_iter=max_iter,
-                              variant=variant, alpha=alpha, damping=damping, clip_llr=clip_llr,
-                              stream=stream.cuda_stream)
+            for a in range(begin, end, step):
+                dec.mc_run_device(code.Lx, code.distance, p, priors[i].data_ptr(), a,
+                                  min(a + step, end), d_table[i].data_ptr(), draws=draws,
+                                  seed=seed, max_iter=max_iter, variant=variant, alpha=alpha,
+                                  damping=damping, clip_llr=clip_llr, flags=flags,
+                                  stream=stream.cuda_stream)
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(d_table)                 # the one RCCL collective of the sweep
@@ -95,6 +99,7 @@ def main(argv=None):
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--damping", type=float, default=1.0)
     ap.add_argument("--clip-llr", type=float, default=20.0)
+    ap.add_argument("--osd", action="store_true", help="OSD-0 on the trials BP does not converge on")
     ap.add_argument("--out", default=None, help="write the counter table as JSON")
     args = ap.parse_args(argv)
 
@@ -112,8 +117,8 @@ def main(argv=None):
     t0 = time.perf_counter()
     table = run_sweep(args.code, args.p, args.trials, draws=args.draws, seed=args.seed,
                       max_iter=args.max_iter, variant=variant, alpha=args.alpha,
-                      damping=args.damping, clip_llr=args.clip_llr, rank=rank, world=world,
-                      device=local)
+                      damping=args.damping, clip_llr=args.clip_llr, osd=args.osd, rank=rank,
+                      world=world, device=local)
     dt = time.perf_counter() - t0
     if rank == 0:
         rows = []
@@ -130,6 +135,7 @@ def main(argv=None):
             with open(args.out, "w") as f:
                 json.dump({"code": args.code, "trials": args.trials, "max_iter": args.max_iter,
                            "draws": args.draws, "seed": args.seed, "variant": args.variant,
+                           "osd": args.osd,
                            "world_size": world, "seconds": dt, "points": rows}, f, indent=1)
     if world > 1:
         import torch.distributed as dist

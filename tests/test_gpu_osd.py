@@ -1,0 +1,81 @@
+"""GPU: OSD-0 (qbp_osd0_batch) against the reference's performOSD outputs and the oracle; the
+BP+OSD Monte-Carlo path against the oracle pipeline and the reference's stored LER curves."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from qldpc_amd import _lib, bp, codes, mc, osd
+from test_oracle_osd import TAGS, load_osd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_device_osd0_matches_reference_goldens(tag):
+    c = load_osd(tag)
+    H = c["H"].astype(np.int64)
+    dec = bp.decoder_for(H)
+    got = dec.osd0(c["syndromes"], c["llr"], c["hard"])
+    assert np.array_equal(got, c["solution"])
+    assert np.array_equal((got.astype(np.int64) @ H.T) % 2, c["syndromes"])
+    one = osd.performOSD(H, c["syndromes"][0], c["llr"][0], c["hard"][0])
+    assert one.dtype == np.int64 and np.array_equal(one, c["solution"][0])
+
+
+def test_device_osd0_vs_oracle_on_bp_failures():
+    code = codes.load_code("[[144, 12, 12]]")
+    dec = bp.decoder_for(code.Hx)
+    rng = np.random.default_rng(12)
+    p = 0.09
+    err = (rng.random((3000, code.n)) < p).astype(np.uint8)
+    syn = (err @ code.Hx.T % 2).astype(np.uint8)
+    hard, conv, iters, llr = dec.decode(syn, mc.prior_of(p, code.n), 30)
+    f = np.flatnonzero(~conv)
+    assert len(f) > 300
+    got = dec.osd0(syn[f], llr[f], hard[f])
+    for i, k in enumerate(f[:400]):
+        assert np.array_equal(got[i], oracle.osd0(code.Hx, syn[k], llr[k], hard[k]))
+    assert np.array_equal((got.astype(np.int64) @ code.Hx.T) % 2, syn[f])
+    # ties: all-equal reliabilities -> index order; zero residual -> solution == hard
+    z = dec.osd0(syn[:4], np.ones((4, code.n)), np.zeros((4, code.n), np.uint8))
+    for i in range(4):
+        assert np.array_equal(z[i], oracle.osd0(code.Hx, syn[i], np.ones(code.n), np.zeros(code.n)))
+    same = dec.osd0(syn[conv][:4], llr[conv][:4], hard[conv][:4])
+    assert np.array_equal(same, hard[conv][:4])
+
+
+@pytest.mark.parametrize("name,p,T", [("[[72, 12, 6]]", 0.06, 2500), ("[[288, 12, 18]]", 0.07, 1200)])
+def test_mc_bp_osd_counters_match_oracle(name, p, T):
+    code = codes.load_code(name)
+    dec = bp.decoder_for(code.Hx)
+    prior = mc.prior_of(p, code.n)
+    got = dec.mc_run(code.Lx, code.distance, p, prior, 5, 5 + T, seed=3, max_iter=50,
+                     flags=_lib.FLAG_OSD0)
+    want = oracle.mc_counters(code.Hx, code.Lx, code.distance, p, prior, 5, 5 + T, seed=3,
+                              max_iter=50, osd=True)
+    print(dict(zip(_lib.COUNTER_NAMES, got.tolist())))
+    # LLRs of non-converged trials differ in the last digits between device and oracle (DESIGN.md
+    # section 2); a different reliability ORDER can change an OSD solution, so allow a few trials
+    assert got[0] == want[0] and got[6] == want[6] and got[7] == want[7] and got[10] == 0
+    assert np.abs(got - want).max() <= max(3, 0.01 * want[6])
+
+
+def test_bp_osd_ler_matches_reference_curves():
+    """BP(50)+OSD-0 logical error rates against the reference's stored curves:
+    data/1-BPOSD.npz (10 000 trials, single draw) and notebooks/data/BPOSD.npz (BP-Fast(50) +
+    OSD-0, 10 000 trials).  100 000 device trials per point; 4 sigma of the combined binomial
+    error (the reference's 10 000 trials dominate)."""
+    grid = np.logspace(-3.2, -1.3, 8)
+    ref = {"[[288, 12, 18]]": {0.06: 0.0596, 0.05: 0.0197, 0.04: 0.0076, float(grid[7]): 0.0225},
+           "[[144, 12, 12]]": {0.06: 0.1121, 0.05: 0.0503, 0.04: 0.0178, float(grid[7]): 0.0499},
+           "[[72, 12, 6]]": {0.06: 0.2541, 0.05: 0.1611, 0.04: 0.0916, float(grid[7]): 0.1629}}
+    T = 100000
+    for name, pts in ref.items():
+        table = mc.run_sweep(name, list(pts), T, seed=2, osd=True)
+        for (p, r), row in zip(pts.items(), table):
+            ler = row[1] / row[0]
+            sigma = np.hypot(np.sqrt(r * (1 - r) / 10000), np.sqrt(r * (1 - r) / T))
+            print(f"{name} p={p:.4f}: BP+OSD LER {ler:.4f} (reference {r}, "
+                  f"{abs(ler - r) / sigma:.1f} sigma), OSD rate {row[6] / row[0]:.4f}")
+            assert row[0] == T and row[10] == 0
+            assert abs(ler - r) <= 4.0 * sigma

@@ -21,7 +21,7 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     header = open(os.path.join(ROOT, "include", "qbp.h")).read()
-    declared = set(re.findall(r"\b(qbp_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(qbp_[a-z0-9_]+)\s*\(", header))
     declared.discard("qbp_handle")
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:

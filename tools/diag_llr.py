@@ -12,7 +12,7 @@ from qldpc_amd import bp, codes  # noqa: E402
 for name, p, B in (("[[144, 12, 12]]", 0.05, 4000), ("[[288, 12, 18]]", 0.05, 3000),
                    ("[[288, 12, 18]]", 0.08, 2000)):
     code = codes.load_code(name)
-    rng = np.random.default_rng(hash((name, p)) % 2**32)
+    rng = np.random.default_rng([code.n, int(p * 1e6)])
     syn = ((rng.random((B, code.n)) < p).astype(np.uint8) @ code.Hx.T % 2).astype(np.uint8)
     prior = np.full(code.n, np.log((1 - p) / p))
     hard, conv, iters, llr = bp.decoder_for(code.Hx).decode(syn, prior, 50)
