@@ -63,6 +63,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("both", "forced"), default="both",
                     help="forced: only the headline mode (profiling runs)")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 "
+                         "path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     args = ap.parse_args()
@@ -75,9 +80,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
