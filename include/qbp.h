@@ -33,7 +33,7 @@ enum {
     QBP_E_INVALID = -1,     /* bad argument (shape, range, null pointer)            */
     QBP_E_NO_DEVICE = -2,   /* no HIP device / device index out of range            */
     QBP_E_HIP = -3,         /* a HIP runtime call failed                            */
-    QBP_E_UNSUPPORTED = -4, /* matrix too large / too dense for the on-chip kernels */
+    QBP_E_UNSUPPORTED = -4, /* operation not available for this matrix (Monte-Carlo / OSD limits) */
     QBP_E_NOMEM = -5
 };
 
@@ -88,6 +88,18 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
                             uint8_t* d_converged, int32_t* d_iters, double* d_llr, void* stream);
 
 /*
+ * Check->variable messages after the check update of iteration `iteration` (0-based), for B
+ * syndromes: messages [B][E] in CSR edge order (host buffers).  This is the `alpha_estimation=True`
+ * return value of the reference, restricted to the edges of H:
+ *   QBP_MIN_SUM   rework/decoding.py:58-59   R_new / alpha at iteration 0
+ *   QBP_DAMPED_SP rework/decoding.py:168-169 R (before scaling by alpha) at iteration 10
+ * (QBP_SUM_PRODUCT is treated as QBP_DAMPED_SP: pass alpha = damping = 1.)
+ */
+int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
+                       int32_t variant, double alpha, double damping, double clip_llr,
+                       int32_t iteration, double* messages);
+
+/*
  * Monte-Carlo trials [trial_begin, trial_end) entirely on the device: sample errors, form
  * syndromes, decode, classify, count.  Replaces the body of the trial loop of
  * paperResults_GPU.py:89-144 (= paperResults.py:57-100) without its OSD call:
@@ -140,6 +152,7 @@ enum {
     QBP_OPT_SLOTS_PER_BLOCK = 1, /* syndromes decoded concurrently by one workgroup (0 = auto) */
     QBP_OPT_BLOCKS_PER_CU = 2,   /* persistent workgroups per CU (0 = auto)                    */
     QBP_OPT_REG_VARIANT = 3,     /* register-budget build of the kernel (0 = auto; tuning)     */
+    QBP_OPT_FORCE_GENERIC = 4,   /* 1 = use the general-H kernel even where the on-chip one fits */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
     QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 fused on-chip, 2 generic */
     QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109

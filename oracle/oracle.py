@@ -47,6 +47,9 @@ def lib():
         L.oracle_mc_errors.restype = None
         L.oracle_mc_errors.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                        C.c_int64, C.c_void_p]
+        L.oracle_bp_check_messages.restype = C.c_int
+        L.oracle_bp_check_messages.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [
+            C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p]
         L.oracle_osd0.restype = C.c_int
         L.oracle_osd0.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 5
         L.oracle_mc_threshold.restype = C.c_uint32
@@ -168,4 +171,19 @@ def osd0(H, syndrome, llr, hard):
                              out.ctypes.data)
     if rank < 0:
         raise MemoryError
+    return out
+
+
+def check_messages(H, syndromes, prior, variant, alpha=1.0, damping=1.0, clip_llr=20.0, iteration=0):
+    """Edge messages float64[B, E] (CSR order): the reference's alpha_estimation=True output."""
+    row_ptr, col_idx, m, n = csr_of(H)
+    syn = np.ascontiguousarray(np.atleast_2d(np.asarray(syndromes)).astype(np.uint8))
+    pr = np.ascontiguousarray(prior, np.float64)
+    out = np.zeros((syn.shape[0], len(col_idx)), np.float64)
+    rc = lib().oracle_bp_check_messages(m, n, row_ptr.ctypes.data, col_idx.ctypes.data,
+                                        syn.ctypes.data, pr.ctypes.data, syn.shape[0], int(variant),
+                                        float(alpha), float(damping), float(clip_llr),
+                                        int(iteration), out.ctypes.data)
+    if rc:
+        raise ValueError(rc)
     return out

@@ -21,7 +21,7 @@ NUM_COUNTERS = 12
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
                  "degenerateErrors", "not_converged", "sum_iterations",
                  "logical_error_not_converged", "exact_recoveries", "osd_invalid", "reserved1")
-OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_REG_VARIANT = 1, 2, 3
+OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_REG_VARIANT, OPT_FORCE_GENERIC = 1, 2, 3, 4
 INFO = dict(m=100, n=101, edges=102, max_row_deg=103, max_col_deg=104, kernel_kind=105,
             threads=106, lds_bytes=107, grid=108, num_cu=109)
 
@@ -43,6 +43,8 @@ SIGNATURES = {
                                     C.c_double, C.c_double, C.c_double, C.c_uint32, _VP, _VP]),
     "qbp_mc_sample_errors": (C.c_int, [_VP, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                        C.c_int64, _VP]),
+    "qbp_check_messages": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                     C.c_double, C.c_int32, _VP]),
     "qbp_osd0_batch": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
     "qbp_osd0_batch_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP]),
     "qbp_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
@@ -162,6 +164,19 @@ class Decoder:
             self._h, Lx.ctypes.data, Lx.shape[0], int(distance), float(p), int(draws), int(seed),
             int(trial_begin), int(trial_end), d_prior, int(max_iter), int(variant), float(alpha),
             float(damping), float(clip_llr), int(flags), d_counters, stream or None))
+
+    def check_messages(self, syndromes, prior, variant, alpha=1.0, damping=1.0, clip_llr=20.0,
+                       iteration=0):
+        """Check->variable messages float64[B, E] (CSR edge order) after iteration `iteration`."""
+        syn = np.ascontiguousarray(syndromes, np.uint8)
+        pr = np.ascontiguousarray(prior, np.float64)
+        if syn.ndim != 2 or syn.shape[1] != self.m or pr.shape != (self.n,):
+            raise ValueError("bad shapes")
+        out = np.empty((syn.shape[0], len(self.col_idx)), np.float64)
+        _check(load().qbp_check_messages(self._h, syn.ctypes.data, pr.ctypes.data, syn.shape[0],
+                                         int(variant), float(alpha), float(damping),
+                                         float(clip_llr), int(iteration), out.ctypes.data))
+        return out
 
     def osd0(self, syndromes, llr, hard):
         """OSD-0 on B decoder outputs (host arrays) -> solution uint8[B, n]."""

@@ -13,6 +13,7 @@
 #include "../../include/qbp.h"
 #include "qbp_kernels.hpp"
 #include "qbp_osd.hpp"
+#include "qbp_generic.hpp"
 
 static_assert(QBP_NUM_COUNTERS == qbp::NUM_COUNTERS, "counter layout");
 
@@ -86,6 +87,11 @@ struct qbp_handle {
     DevBuf<long long> d_counters;
     std::vector<uint8_t> lx_cache;   // last uploaded Lx (host copy) to skip re-uploads
     int lx_cache_k = -1;
+    // general-H kernel
+    DevBuf<int32_t> d_col_ptr, d_col_edge;
+    DevBuf<double> d_wsQ, d_wsR, d_wsV;
+    DevBuf<uint8_t> d_wsC;
+    int opt_force_generic = 0;
     // OSD-0
     bool osd_ok = false;
     int osd_W = 0, osd_NP = 0, osd_lds = 0;
@@ -180,7 +186,7 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     return QBP_OK;
 }
 
-int check_decode_args(qbp_handle* h, long long B, int max_iter, int variant)
+int check_decode_args(qbp_handle* h, long long B, int max_iter, int variant, bool need_fused = false)
 {
     if (!h) return fail(QBP_E_INVALID, "null handle");
     if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0 (got %lld)", B);
@@ -188,7 +194,7 @@ int check_decode_args(qbp_handle* h, long long B, int max_iter, int variant)
         return fail(QBP_E_INVALID, "max_iter must be >= 1 (got %d); the reference raises "
                                    "UnboundLocalError for maxIter=0", max_iter);
     if (variant < 0 || variant > 2) return fail(QBP_E_INVALID, "unknown variant %d", variant);
-    if (!h->fused_ok)
+    if (need_fused && !h->fused_ok)
         return fail(QBP_E_UNSUPPORTED,
                     "H (m=%d, max row degree %d, max column degree %d) does not fit the on-chip "
                     "kernel (m <= 1024, row degree <= %d, column degree <= %d)",
@@ -297,6 +303,17 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
         up(h->d_tab_writer, tab_writer);
     }
     up(h->d_iso, iso);
+    {   // CSR + CSC (edge ids per column, ascending check) for the general-H kernel
+        std::vector<int32_t> col_ptr(n + 1, 0), col_edge((size_t)std::max(E, 1));
+        for (int v = 0; v < n; ++v) col_ptr[v + 1] = col_ptr[v] + (int)cols[v].size();
+        for (int v = 0; v < n; ++v)
+            for (size_t k = 0; k < cols[v].size(); ++k)
+                col_edge[col_ptr[v] + k] = row_ptr[cols[v][k].first] + cols[v][k].second;
+        up(h->d_col_ptr, col_ptr);
+        up(h->d_col_edge, col_edge);
+        up(h->d_row_ptr, h->row_ptr);
+        up(h->d_col_idx, h->col_idx);
+    }
     {   // OSD-0: bit-packed rows of H and its CSR
         const int W = (n + 31) / 32;
         int NP = 1;
@@ -310,8 +327,6 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
                 for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e)
                     hbits[(size_t)c * W + (col_idx[e] >> 5)] |= 1u << (col_idx[e] & 31);
             up(h->d_hbits, hbits);
-            up(h->d_row_ptr, h->row_ptr);
-            up(h->d_col_idx, h->col_idx);
         }
     }
     if (e1 == hipSuccess) e1 = h->d_work_counter.reserve(1);
@@ -335,10 +350,43 @@ void qbp_destroy(qbp_handle* h)
     h->d_work_counter.release(); h->d_syn.release(); h->d_hard.release(); h->d_conv.release();
     h->d_lx_bytes.release(); h->d_iters.release(); h->d_llr.release(); h->d_prior.release();
     h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
+    h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
+    h->d_wsV.release(); h->d_wsC.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
     delete h;
+}
+
+static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior, int64_t B,
+                          int max_iter, int variant, double alpha, double damping, double clip_llr,
+                          unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
+                          double* d_llr, double* d_dump, int dump_iter, double dump_div, hipStream_t s)
+{
+    // general-H kernel: one workgroup per syndrome, messages in a global workspace
+    const int grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * 4));
+    const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
+    HIP_TRY(h->d_wsQ.reserve((size_t)grid * E));
+    HIP_TRY(h->d_wsR.reserve((size_t)grid * E));
+    HIP_TRY(h->d_wsV.reserve((size_t)grid * n));
+    HIP_TRY(h->d_wsC.reserve((size_t)grid * n));
+    qbp::GenericParams G{};
+    G.m = h->m; G.n = h->n; G.E = h->E;
+    G.row_ptr = h->d_row_ptr.p; G.col_idx = h->d_col_idx.p;
+    G.col_ptr = h->d_col_ptr.p; G.col_edge = h->d_col_edge.p;
+    G.syndromes = d_syndromes; G.prior = d_prior; G.B = B; G.max_iter = max_iter; G.flags = flags;
+    G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
+    G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
+    G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p; G.wsV = h->d_wsV.p; G.wsC = h->d_wsC.p;
+    G.dump_R = d_dump; G.dump_iter = dump_iter; G.dump_div = dump_div;
+    h->last_threads = 256; h->last_lds = 0; h->last_grid = grid;
+    switch (variant) {
+        case QBP_SUM_PRODUCT: hipLaunchKernelGGL(qbp::bp_generic_kernel<0>, dim3(grid), dim3(256), 0, s, G); break;
+        case QBP_DAMPED_SP:   hipLaunchKernelGGL(qbp::bp_generic_kernel<1>, dim3(grid), dim3(256), 0, s, G); break;
+        default:              hipLaunchKernelGGL(qbp::bp_generic_kernel<2>, dim3(grid), dim3(256), 0, s, G); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return QBP_OK;
 }
 
 int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior,
@@ -353,6 +401,9 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     if (B > (int64_t)1 << 40) return fail(QBP_E_INVALID, "B too large");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!h->fused_ok || h->opt_force_generic)
+        return generic_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr,
+                              flags, d_hard, d_converged, d_iters, d_llr, nullptr, 0, 1.0, s);
     LaunchCfg cfg;
     rc = make_cfg(h, B, &cfg);
     if (rc) return rc;
@@ -396,6 +447,35 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
     if (converged) HIP_TRY(hipMemcpyAsync(converged, h->d_conv.p, b, hipMemcpyDeviceToHost, s));
     if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters.p, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (llr) HIP_TRY(hipMemcpyAsync(llr, h->d_llr.p, b * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return QBP_OK;
+}
+
+int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
+                       int32_t variant, double alpha, double damping, double clip_llr,
+                       int32_t iteration, double* messages)
+{
+    int rc = check_decode_args(h, B, iteration + 1, variant);
+    if (rc) return rc;
+    if (variant == QBP_SUM_PRODUCT) variant = QBP_DAMPED_SP;   // same update with alpha=damping=1
+    if (B == 0) return QBP_OK;
+    if (!syndromes || !prior || !messages) return fail(QBP_E_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t m = h->m, n = h->n, b = (size_t)B, E = (size_t)std::max(h->E, 1);
+    HIP_TRY(h->d_syn.reserve(b * m));
+    HIP_TRY(h->d_prior.reserve(n));
+    HIP_TRY(h->d_llr.reserve(b * E));
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->d_syn.p, syndromes, b * m, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior, n * sizeof(double), hipMemcpyHostToDevice, s));
+    // min-sum returns R_new / alpha (rework/decoding.py:58-59); damped SP the unscaled R (:168-169,
+    // taken before R * alpha)
+    const double div = variant == QBP_MIN_SUM ? alpha : 1.0;
+    rc = generic_launch(h, h->d_syn.p, h->d_prior.p, B, iteration + 1, variant, alpha, damping, clip_llr,
+                        QBP_FLAG_FORCE_FULL /* no early exit before the dump iteration */, nullptr,
+                        nullptr, nullptr, nullptr, h->d_llr.p, iteration, div, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(messages, h->d_llr.p, b * (size_t)h->E * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
@@ -485,7 +565,7 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
                       uint32_t flags, int64_t* d_counters, void* stream)
 {
     const int64_t T = trial_end - trial_begin;
-    int rc = check_decode_args(h, T, max_iter, variant);
+    int rc = check_decode_args(h, T, max_iter, variant, /*need_fused=*/true);
     if (rc) return rc;
     if (trial_begin < 0) return fail(QBP_E_INVALID, "trial_begin must be >= 0");
     if (draws != 1 && draws != 2) return fail(QBP_E_INVALID, "draws must be 1 or 2 (got %d)", draws);
@@ -567,7 +647,7 @@ int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, do
 int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
                          int64_t trial_begin, int64_t T, uint8_t* errors)
 {
-    int rc = check_decode_args(h, T, 1, 0);
+    int rc = check_decode_args(h, T, 1, 0, /*need_fused=*/true);
     if (rc) return rc;
     if (!errors) return fail(QBP_E_INVALID, "errors is null");
     if (draws != 1 && draws != 2) return fail(QBP_E_INVALID, "draws must be 1 or 2");
@@ -610,6 +690,8 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 32) return fail(QBP_E_INVALID, "blocks per CU out of range");
             h->opt_blocks_per_cu = (int)value; return QBP_OK;
+        case QBP_OPT_FORCE_GENERIC:
+            h->opt_force_generic = value != 0; return QBP_OK;
         case QBP_OPT_REG_VARIANT:
             if (value < 0 || value > 4) return fail(QBP_E_INVALID, "register variant out of range");
             h->opt_reg_variant = (int)value; return QBP_OK;
@@ -626,7 +708,7 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
         case QBP_INFO_EDGES: return h->E;
         case QBP_INFO_MAX_ROW_DEG: return h->max_row_deg;
         case QBP_INFO_MAX_COL_DEG: return h->max_col_deg;
-        case QBP_INFO_KERNEL_KIND: return h->fused_ok ? 1 : 2;
+        case QBP_INFO_KERNEL_KIND: return (h->fused_ok && !h->opt_force_generic) ? 1 : 2;
         case QBP_INFO_THREADS: return h->last_threads;
         case QBP_INFO_LDS_BYTES: return h->last_lds;
         case QBP_INFO_GRID: return h->last_grid;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // chunks of WORK_CHUNK consecutive indices from one global counter (one returning atomic per
     // WORK_CHUNK syndromes: a single word sustains only ~88 dequeues/us, MI355X_MICROARCH.md
     // 'dequeue', which early-exit decoding at low error rates would exceed).
-    constexpr int WORK_CHUNK = 8;
+    constexpr int WORK_CHUNK = FORCE_FULL ? 1 : 8;   // forced mode: 1 atomic per max_iter iterations
     long long chunk_end = 0;      // leader only: end of the chunk next_work[slot] points into
     long long b = lane_valid ? (long long)blockIdx.x * S + slot : B;
     bool active = b < B;
@@ -462,7 +462,14 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 __global__ void debug_math_kernel(int kind, const double* x, double* y, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = kind == 0 ? tanh_half(x[i]) : atanh2(x[i]);
+    if (i >= n) return;
+    const double v = x[i];
+    switch (kind) {
+        case 0: y[i] = tanh_half(v); break;
+        case 1: y[i] = atanh2(v); break;
+        case 2: y[i] = __builtin_amdgcn_rcp(v); break;          // raw v_rcp_f64 (seed accuracy)
+        default: y[i] = div_nr(1.0, v); break;
+    }
 }
 
 }  // namespace qbp

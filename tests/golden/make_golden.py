@@ -159,5 +159,56 @@ def main():
         print(f"wrote {path}: {os.path.getsize(path)} bytes, {len(manifest)} cases")
 
 
+def irregular():
+    """Matrices beyond the (row weight 6, column weight 3) shape of codes/*.npz: the reference's
+    space-time matrix (spaceTime.py:4-18, used by studies/studyTT.py:33-49) and a random sparse
+    matrix with wide rows/columns and per-variable priors (studies/studyComplete.py:88-89)."""
+    sys.path.insert(0, REF)
+    from spaceTime import spaceTimeMatrix, spacetimeSyndrome
+    H72 = np.load(os.path.join(REF, "codes", "[[72, 12, 6]].npz"))["Hx"]
+    cases = {}
+    np.random.seed(20260128)
+    Hst = spaceTimeMatrix(H72, 3)                      # (108, 324) float 0/1
+    cases["st72"] = (Hst, [spacetimeSyndrome(H72, 0.02, 3)[1] for _ in range(12)]
+                     + [spacetimeSyndrome(H72, 0.06, 3)[1] for _ in range(8)], None)
+    rng = np.random.default_rng(SEED)
+    m, n = 60, 120
+    Hr = np.zeros((m, n), np.int64)
+    for c in range(m):
+        Hr[c, rng.choice(n, rng.integers(2, 13), replace=False)] = 1
+    Hr[:, 5] = 0                                       # an isolated variable
+    Hr[7, :] = 0                                       # an empty check
+    pv = rng.uniform(0.01, 0.2, n)
+    e = (rng.random((24, n)) < pv * 0.5).astype(np.int64)
+    cases["rand"] = (Hr, list((e @ Hr.T) % 2), np.log((1 - pv) / pv))
+    for tag, (H, syns, prior) in cases.items():
+        m, n = H.shape
+        syns = np.array(syns).astype(np.int64)
+        arrays, manifest = {}, []
+        pr = prior if prior is not None else prior_of(0.03, n)
+        for fn, mi, kw in (("fast4", 50, {}), ("fast4", 5, {}),
+                           ("minsum", 50, dict(alpha=0.8, damping=0.7, clip_llr=25.0)),
+                           ("sym", 50, {})):
+            hard, conv, iters, llr = run_single(fn, H, syns, pr, mi, **kw)
+            k = f"case{len(manifest):02d}"
+            arrays[f"{k}/syndromes"] = syns.astype(np.uint8)
+            arrays[f"{k}/prior"] = np.asarray(pr, np.float64)
+            arrays[f"{k}/hard"] = hard.astype(np.uint8)
+            arrays[f"{k}/converged"] = conv.astype(np.uint8)
+            arrays[f"{k}/iters"] = iters.astype(np.int32)
+            arrays[f"{k}/llr"] = llr
+            manifest.append(dict(key=k, fn=fn, max_iter=mi, note=tag, kw=kw,
+                                 n_converged=int(conv.sum()), B=int(len(conv))))
+            print(f"  {tag} {k} {fn:6s} maxIter={mi:3d} B={len(conv):3d} converged={int(conv.sum()):3d} "
+                  f"row wt<= {int(H.sum(1).max())} col wt<= {int(H.sum(0).max())}")
+        arrays["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+        arrays["H"] = (np.asarray(H) != 0).astype(np.uint8)
+        path = os.path.join(HERE, f"bp_{tag}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"wrote {path}: {os.path.getsize(path)} bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--irregular-only" not in sys.argv:
+        main()
+    irregular()

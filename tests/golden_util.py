@@ -6,6 +6,8 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TAGS = ("steane", "72", "90", "108", "144", "288")
+# matrices beyond the on-chip kernel: reference space-time matrix, random wide sparse matrix
+IRREGULAR_TAGS = ("st72", "rand")
 VARIANT = {"fast3": 0, "loop3": 0, "fast4": 0, "batch": 0, "sym": 1, "minsum": 2}
 # argument defaults of the reference functions (rework/decoding.py:5 and :131)
 DEFAULTS = {"minsum": dict(alpha=1.0, damping=1.0, clip_llr=20.0),

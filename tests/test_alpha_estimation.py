@@ -1,0 +1,55 @@
+"""alpha_estimation=True message dumps (rework/decoding.py:58-59, :168-169) and the alpha fit of
+rework/Alvarado.py:10-66: oracle on CPU, device + Python mirrors on GPU, against vectors produced
+by the reference's decoders (tests/golden/alpha_est.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alpha_est.npz")
+
+
+def gold():
+    return np.load(GOLD)
+
+
+def test_oracle_message_dumps_match_reference():
+    d = gold()
+    H = d["H"].astype(np.int64)
+    a = oracle.check_messages(H, d["syndromes"], d["prior"], 2, 1.0, 1.0, np.inf, 0)
+    assert np.array_equal(a, d["minsum_R"])                  # no transcendental: bit-exact
+    b = oracle.check_messages(H, d["syndromes"], d["prior_nu"], 2, 0.8, 0.7, 25.0, 0)
+    assert np.array_equal(b, d["minsum_nu_R"])
+    c = oracle.check_messages(H, d["syndromes"], d["prior_nu"], 1, 0.9, 0.8, 20.0, 10)
+    np.testing.assert_allclose(c, d["sym_R"], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_device_message_dumps_and_alpha_fit(capsys):
+    from qldpc_amd import _lib, alvarado, bp, rework
+    d = gold()
+    H = d["H"].astype(np.int64)
+    dec = bp.decoder_for(H)
+    a = dec.check_messages(d["syndromes"], d["prior"], _lib.MIN_SUM, 1.0, 1.0, np.inf, 0)
+    assert np.array_equal(a, d["minsum_R"])
+    b = dec.check_messages(d["syndromes"], d["prior_nu"], _lib.MIN_SUM, 0.8, 0.7, 25.0, 0)
+    assert np.array_equal(b, d["minsum_nu_R"])
+    c = dec.check_messages(d["syndromes"], d["prior_nu"], _lib.DAMPED_SP, 0.9, 0.8, 20.0, 10)
+    np.testing.assert_allclose(c, d["sym_R"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(c, oracle.check_messages(H, d["syndromes"], d["prior_nu"], 1, 0.9, 0.8,
+                                                        20.0, 10), rtol=1e-9, atol=1e-12)
+    # reference-shaped return value: (0, 0, dense R, 0)
+    out = rework.performMinSum_Symmetric(H, d["syndromes"][0], list(d["prior"]), maxIter=1, alpha=1.0,
+                                         damping=1.0, clip_llr=np.inf, alpha_estimation=True)
+    rows, cols = np.nonzero(H)
+    assert out[0] == 0 and out[1] == 0 and out[3] == 0 and out[2].shape == H.shape
+    assert np.array_equal(out[2][rows, cols], d["minsum_R"][0]) and out[2][H == 0].sum() == 0
+    # the alpha fit with the reference's RNG stream
+    trials, error_rate, bins, seed = d["alpha_fit_args"]
+    np.random.seed(int(seed))
+    alpha = alvarado.estimate_alpha_from_code(H, trials=int(trials), error_rate=float(error_rate),
+                                              maxIter=1, bins=int(bins))
+    assert "Estimated alpha for error rate" in capsys.readouterr().out
+    assert alpha == pytest.approx(float(d["alpha_fit"][0]), rel=1e-12)

@@ -100,3 +100,20 @@ def test_dropin_package_resolution(tmp_path):
     (ref / "run.py").write_text(script)
     out = subprocess.check_output([sys.executable, str(ref / "run.py")], env=env, cwd=ref, text=True)
     assert out.split() == ["qldpc_amd.bp", "qldpc_amd.osd", "ref-osd-w"]
+
+
+def test_results_writer_schema(tmp_path):
+    """The result file keeps the reference's layout (paperResults_GPU.py:156-166) so that
+    loadResults.py-style readers work: results[code][key] is a list over the error rates."""
+    from qldpc_amd import paper_results
+    tables = {"[[72, 12, 6]]": np.array([[1000, 12, 0, 1, 11, 30, 40, 900, 10, 800, 0, 0],
+                                          [1000, 2, 0, 0, 2, 5, 3, 100, 1, 950, 0, 0]], np.int64)}
+    res = paper_results.results_from_tables(tables)
+    path = paper_results.save_results(str(tmp_path / "out"), res, dict(physicalErrorRates=[0.05, 0.01]))
+    loaded = np.load(path, allow_pickle=True)["results"].item()          # loadResults.py:5-7
+    assert set(loaded["[[72, 12, 6]]"]) == set(paper_results.KEYS)
+    assert loaded["[[72, 12, 6]]"]["ler"] == [0.012, 0.002]
+    assert loaded["[[72, 12, 6]]"]["degeneracies"] == [30, 5]
+    assert loaded["[[72, 12, 6]]"]["BPs_fault"] == [0, 0]
+    back, meta = paper_results.load_results(path)
+    assert back == loaded and meta["physicalErrorRates"] == [0.05, 0.01]

@@ -6,7 +6,7 @@ import golden_util
 from oracle import oracle
 
 
-@pytest.mark.parametrize("tag", golden_util.TAGS)
+@pytest.mark.parametrize("tag", golden_util.TAGS + golden_util.IRREGULAR_TAGS)
 def test_oracle_matches_reference_goldens(tag):
     n_cases = 0
     worst = (0.0, 0.0)
@@ -17,7 +17,7 @@ def test_oracle_matches_reference_goldens(tag):
         w = golden_util.compare(case, hard, conv, iters, llr, "oracle")
         worst = (max(worst[0], w[0]), max(worst[1], w[1]))
         n_cases += 1
-    assert n_cases >= 10
+    assert n_cases >= (4 if tag in golden_util.IRREGULAR_TAGS else 10)
     print(f"{tag}: {n_cases} cases, worst LLR rel err converged {worst[0]:.2e}, "
           f"non-converged {worst[1]:.2e}")
 
