@@ -161,7 +161,7 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value);
 int64_t qbp_get_info(qbp_handle* h, int32_t what);
 
 /* Device evaluation of the kernels' FP64 elementary functions, for accuracy tests:
- * kind 0: tanh(x/2), kind 1: 2*atanh(x).  Host buffers. */
+ * kind 0: tanh(x/2), 1: 2*atanh(x), 2: raw v_rcp_f64(x), 3: div_nr(1, x).  Host buffers. */
 int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int64_t count);
 
 const char* qbp_last_error(void);

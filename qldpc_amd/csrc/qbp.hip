@@ -719,7 +719,7 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
 
 int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int64_t count)
 {
-    if (!h || !x || !y || count < 0 || kind < 0 || kind > 1) return fail(QBP_E_INVALID, "bad arguments");
+    if (!h || !x || !y || count < 0 || kind < 0 || kind > 3) return fail(QBP_E_INVALID, "bad arguments");
     if (count == 0) return QBP_OK;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(h->d_mathx.reserve((size_t)count));

@@ -303,11 +303,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         double val[DC];
         if (active) {
             bool odd = sbit != 0;                                 // parity of the row vs syndrome
+            // issue all DC*DV LDS gathers before the first add (one lgkmcnt wait instead of DC*2)
+            double rr[DC][DV];
+#pragma unroll
+            for (int j = 0; j < DC; ++j)
+#pragma unroll
+                for (int k = 0; k < DV; ++k) rr[j][k] = Rs[nbr[j][k]];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < DC; ++j) {
-                double s = Rs[nbr[j][0]];
+                double s = rr[j][0];
 #pragma unroll
-                for (int k = 1; k < DV; ++k) s = s + Rs[nbr[j][k]];   // ascending check order
+                for (int k = 1; k < DV; ++k) s = s + rr[j][k];   // ascending check order
                 val[j] = s + pri[j];
                 odd ^= val[j] < 0.0;                              // hard decision: values < 0
                 const double qn = val[j] - R[j];

@@ -38,7 +38,11 @@
 #define QBP_RINT(x) std::nearbyint(x)
 #else
 #define QBP_HD inline
+#ifdef QBP_TEST_SEED_ERR   /* host tests: emulate the 2^-24.4 accuracy of v_rcp_f64 */
+#define QBP_RCP(x) ((1.0 / (x)) * (1.0 + (QBP_TEST_SEED_ERR)))
+#else
 #define QBP_RCP(x) (1.0 / (x))
+#endif
 #define QBP_LDEXP(x, e) std::ldexp(x, e)
 #define QBP_FREXP_EXP(x) (std::ilogb(x) + 1)
 #define QBP_RINT(x) std::nearbyint(x)
@@ -77,17 +81,19 @@ QBP_HD int frexp_exp_pos(double x)
 #endif
 }
 
-// a / b for normal b with a / b neither overflowing nor subnormal: reciprocal seed, two
-// Newton steps, one residual correction (the core of the IEEE sequence, without scaling).
+// a / b for normal b with a / b neither overflowing nor subnormal.  v_rcp_f64 is accurate to
+// 2^-24.4 (measured on gfx950, tools/measure_misc.py); one Newton step brings the reciprocal to
+// 2^-48; the quotient a*r then has that relative error and the residual correction
+// q + (a - b q) r squares it away (2^-97 before the final rounding), i.e. the result is the
+// correctly rounded quotient except when the exact quotient lies within 2^-97 of a rounding
+// boundary.  (The IEEE sequence spends a second Newton step and operand scaling on top of this.)
 QBP_HD double div_nr(double a, double b)
 {
     double r = QBP_RCP(b);
-    double e = __builtin_fma(-b, r, 1.0);
+    const double e = __builtin_fma(-b, r, 1.0);
     r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-b, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    double q = a * r;
-    double rem = __builtin_fma(-b, q, a);
+    const double q = a * r;
+    const double rem = __builtin_fma(-b, q, a);
     return __builtin_fma(rem, r, q);
 }
 

@@ -11,16 +11,23 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def shim():
+def _build(tag, extra):
     src = os.path.join(HERE, "_shim", "math_host_shim.cpp")
-    so = os.path.join(HERE, "_shim", "libmathshim.so")
+    so = os.path.join(HERE, "_shim", f"libmathshim{tag}.so")
     hdr = os.path.join(HERE, "..", "qldpc_amd", "csrc", "qbp_math.hpp")
     if (not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src),
                                                              os.path.getmtime(hdr))):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-mfma",
-                               "-ffp-contract=off", "-o", so, src])
+                               "-ffp-contract=off", *extra, "-o", so, src])
     return C.CDLL(so)
+
+
+# The device seeds its divisions with v_rcp_f64 (relative error up to 2^-24.4 = 4.6e-8, measured);
+# the host build's seed is exact, so the suite also runs with the seed perturbed by +-5e-8.
+@pytest.fixture(scope="module", params=["", "_p", "_m"])
+def shim(request):
+    extra = {"": [], "_p": ["-DQBP_TEST_SEED_ERR=5e-8"], "_m": ["-DQBP_TEST_SEED_ERR=-5e-8"]}
+    return _build(request.param, extra[request.param])
 
 
 def _call(fn, x):
@@ -85,12 +92,13 @@ def test_atanh2_ulp(shim):
 
 def test_div_nr(shim):
     rng = np.random.default_rng(3)
-    a = rng.uniform(-2, 2, 20000)
-    b = rng.uniform(1e-7, 4, 20000)
+    a = rng.uniform(-2, 2, 400000)
+    b = np.concatenate([rng.uniform(1e-7, 4, 200000), 10.0 ** rng.uniform(-15, 0, 200000)])
     y = np.empty_like(a)
     shim.shim_div(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                   y.ctypes.data_as(C.c_void_p), C.c_long(a.size))
     exact = a / b
     ulps = np.abs(y - exact) / np.spacing(np.abs(exact))
     assert ulps.max() <= 1.0
-    print(f"div_nr: {np.mean(y == exact) * 100:.2f}% correctly rounded, worst {ulps.max():.1f} ulp")
+    assert np.mean(y == exact) >= 0.99999
+    print(f"div_nr: {np.mean(y == exact) * 100:.4f}% correctly rounded, worst {ulps.max():.1f} ulp")

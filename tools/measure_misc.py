@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""GPU box: (1) accuracy of the raw v_rcp_f64 seed and of div_nr; (2) general-H kernel throughput;
+(3) OSD-0 throughput; (4) Monte-Carlo throughput incl. sampling + classification."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qldpc_amd import _lib, bp, codes, mc  # noqa: E402
+
+code = codes.load_code("[[288, 12, 18]]")
+dec = bp.decoder_for(code.Hx)
+rng = np.random.default_rng(0)
+x = np.concatenate([rng.uniform(1, 2, 2_000_000), 10.0 ** rng.uniform(-7, 2, 1_000_000)])
+r = dec.debug_math(2, x)
+rel = np.abs(r * x - 1.0)
+print(f"v_rcp_f64 seed: max |x*rcp(x)-1| = {rel.max():.3e} = 2^{np.log2(rel.max()):.2f}; "
+      f"fraction exact RN(1/x): {np.mean(r == 1.0 / x):.4f}")
+d = dec.debug_math(3, x)
+print(f"div_nr(1, x) == 1/x (IEEE): {np.mean(d == 1.0 / x) * 100:.5f}% of {x.size}")
+
+# general-H kernel on the 288 code, forced 50
+p = 0.01
+B = 20000
+syn = ((rng.random((B, code.n)) < p).astype(np.uint8) @ code.Hx.T % 2).astype(np.uint8)
+prior = mc.prior_of(p, code.n)
+for force in (0, 1):
+    dec.set_option(_lib.OPT_FORCE_GENERIC, force)
+    dec.decode(syn[:100], prior, 50, flags=_lib.FLAG_FORCE_FULL)
+    t0 = time.perf_counter()
+    dec.decode(syn, prior, 50, flags=_lib.FLAG_FORCE_FULL, want_llr=False)
+    dt = time.perf_counter() - t0
+    print(f"{'general-H' if force else 'fused'} kernel via host API (incl. PCIe): {B / dt:.3e} syndromes/s forced 50")
+dec.set_option(_lib.OPT_FORCE_GENERIC, 0)
+
+# OSD-0 throughput
+hard, conv, iters, llr = dec.decode(syn, prior, 3)
+f = np.flatnonzero(~conv)[:5000]
+if len(f) < 1000:
+    p2 = 0.08
+    syn2 = ((rng.random((5000, code.n)) < p2).astype(np.uint8) @ code.Hx.T % 2).astype(np.uint8)
+    hard, conv, iters, llr = dec.decode(syn2, mc.prior_of(p2, code.n), 10)
+    f = np.flatnonzero(~conv)
+    syn = syn2
+dec.osd0(syn[f[:64]], llr[f[:64]], hard[f[:64]])
+t0 = time.perf_counter()
+dec.osd0(syn[f], llr[f], hard[f])
+dt = time.perf_counter() - t0
+print(f"OSD-0 via host API: {len(f) / dt:.3e} syndromes/s ({len(f)} BP failures)")
+
+# Monte-Carlo end to end (sampling + decode + classify), early exit
+for pp, osd in ((0.01, False), (0.05, False), (0.05, True)):
+    T = 1_000_000 if not osd else 1 << 20
+    pr = mc.prior_of(pp, code.n)
+    dec.mc_run(code.Lx, code.distance, pp, pr, 0, 10000, flags=_lib.FLAG_OSD0 if osd else 0)
+    t0 = time.perf_counter()
+    c = dec.mc_run(code.Lx, code.distance, pp, pr, 0, T, flags=_lib.FLAG_OSD0 if osd else 0)
+    dt = time.perf_counter() - t0
+    print(f"qbp_mc_run p={pp} osd={osd}: {T / dt:.3e} trials/s, LER {c[1] / c[0]:.5f}, "
+          f"not converged {c[6] / c[0]:.4f}, mean iters {c[7] / c[0] + 1:.2f}")
