@@ -102,6 +102,20 @@ __device__ __forceinline__ unsigned mc_error_bit(unsigned long long trial, int v
     return bit;
 }
 
+// Rarely used launch parameters (output pointers, Monte-Carlo settings, ...) are re-read from the
+// kernel-argument segment where they are needed instead of being kept in SGPRs for the whole
+// kernel: the hot loop already needs ~60 SGPRs for FP64 constants, and every SGPR the compiler
+// has to spill costs v_readlane/v_writelane slots on the (saturated) vector ALU.  The empty asm
+// makes the pointer opaque so that the loads cannot be hoisted out of the cold branches.
+typedef const FusedParams __attribute__((address_space(4)))* ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args()
+{
+    ColdArgs p = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define COLD(field) (cold_args()->field)
+
 __device__ __forceinline__ double clipd(double x, double lo, double hi)
 {   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi): v_max_f64 + v_min_f64
     return __builtin_fmin(__builtin_fmax(x, lo), hi);
@@ -225,16 +239,16 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
         for (int j = 0; j < DC; ++j) Q[j] = pri[j];      // Q = where(mask, initialBelief, 0)
         if constexpr (MC) {
-            const unsigned long long trial = (unsigned long long)(P.trial_begin + b);
+            const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
             ebits = 0;
 #pragma unroll 1
             for (int j = 0; j < DC; ++j) {        // once per trial: keep it out of the registers
                 const int v = P.tab_var[j * m + c];
-                if (v >= 0) ebits |= mc_error_bit(trial, v, P.draws, P.seed, P.threshold) << j;
+                if (v >= 0) ebits |= mc_error_bit(trial, v, COLD(draws), COLD(seed), COLD(threshold)) << j;
             }
             sbit = __builtin_popcount(ebits) & 1u;       // syndrome = H e mod 2
         } else {
-            sbit = P.syndromes[b * m + c] & 1u;
+            sbit = COLD(syndromes)[b * m + c] & 1u;
         }
     };
     bool need_start = active;     // (re)initialise at the loop top, where Q / val / R are dead
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 long long nx = next_work[slot] + 1;
                 if (nx == chunk_end) {
                     nx = total_slots +
-                         (long long)atomicAdd(P.work_counter, (unsigned long long)WORK_CHUNK);
+                         (long long)atomicAdd(COLD(work_counter), (unsigned long long)WORK_CHUNK);
                     chunk_end = nx + WORK_CHUNK;
                 }
                 next_work[slot] = nx;
@@ -347,8 +361,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             if constexpr (MC) {
                 if (mc_pending) {
                     mc_classify(mc_lmask, mc_weight, mc_diff, mc_count, slot, mc_pending_conv,
-                                mc_pending_it, P.half_distance,
-                                P.fail_list != nullptr && !mc_pending_conv);
+                                mc_pending_it, COLD(half_distance),
+                                COLD(fail_list) != nullptr && !mc_pending_conv);
                     mc_pending = false;
                 }
             }
@@ -361,27 +375,27 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             const bool last = it == max_iter - 1;
             if (!frozen && (conv || last)) {
                 if constexpr (MC) {
-                    const unsigned long long trial = (unsigned long long)(P.trial_begin + b);
-                    if (P.fail_list != nullptr && !conv) {
+                    const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
+                    if (COLD(fail_list) != nullptr && !conv) {
                         // BP failed: leave the trial to the OSD kernel (record indexed by b)
-                        P.fail_syn[b * m + c] = (uint8_t)sbit;
+                        COLD(fail_syn)[b * m + c] = (uint8_t)sbit;
 #pragma unroll
                         for (int j = 0; j < DC; ++j) {
                             if ((wmask >> j) & 1u) {
-                                const long long o = b * P.n + var[j];
-                                P.fail_llr[o] = val[j];
-                                P.fail_hard[o] = (uint8_t)(val[j] < 0.0);
-                                P.fail_err[o] = (uint8_t)((ebits >> j) & 1u);
+                                const long long o = b * COLD(n) + var[j];
+                                COLD(fail_llr)[o] = val[j];
+                                COLD(fail_hard)[o] = (uint8_t)(val[j] < 0.0);
+                                COLD(fail_err)[o] = (uint8_t)((ebits >> j) & 1u);
                             }
                         }
-                        for (int i = c; i < P.n_iso; i += m) {
-                            const int v = P.iso_vars[i];
-                            const long long o = b * P.n + v;
-                            P.fail_llr[o] = P.prior[v];
-                            P.fail_hard[o] = (uint8_t)(P.prior[v] < 0.0);
-                            P.fail_err[o] = (uint8_t)mc_error_bit(trial, v, P.draws, P.seed, P.threshold);
+                        for (int i = c; i < COLD(n_iso); i += m) {
+                            const int v = COLD(iso_vars)[i];
+                            const long long o = b * COLD(n) + v;
+                            COLD(fail_llr)[o] = COLD(prior)[v];
+                            COLD(fail_hard)[o] = (uint8_t)(COLD(prior)[v] < 0.0);
+                            COLD(fail_err)[o] = (uint8_t)mc_error_bit(trial, v, COLD(draws), COLD(seed), COLD(threshold));
                         }
-                        if (c == 0) P.fail_list[atomicAdd(P.fail_count, 1ull)] = b;
+                        if (c == 0) COLD(fail_list)[atomicAdd(COLD(fail_count), 1ull)] = b;
                     } else {
                     unsigned long long lm = 0ull;
                     int ew = 0;
@@ -393,18 +407,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                             const unsigned res = (val[j] < 0.0 ? 1u : 0u) ^ e;
                             ew += (int)e;
                             df |= res;
-                            if (res) lm ^= P.lx_cols[var[j]];
-                            if (P.errors_out) P.errors_out[b * P.n + var[j]] = (uint8_t)e;
+                            if (res) lm ^= COLD(lx_cols)[var[j]];
+                            if (COLD(errors_out)) COLD(errors_out)[b * COLD(n) + var[j]] = (uint8_t)e;
                         }
                     }
-                    for (int i = c; i < P.n_iso; i += m) {
-                        const int v = P.iso_vars[i];
-                        const unsigned e = mc_error_bit(trial, v, P.draws, P.seed, P.threshold);
-                        const unsigned res = (P.prior[v] < 0.0 ? 1u : 0u) ^ e;
+                    for (int i = c; i < COLD(n_iso); i += m) {
+                        const int v = COLD(iso_vars)[i];
+                        const unsigned e = mc_error_bit(trial, v, COLD(draws), COLD(seed), COLD(threshold));
+                        const unsigned res = (COLD(prior)[v] < 0.0 ? 1u : 0u) ^ e;
                         ew += (int)e;
                         df |= res;
-                        if (res) lm ^= P.lx_cols[v];
-                        if (P.errors_out) P.errors_out[b * P.n + v] = (uint8_t)e;
+                        if (res) lm ^= COLD(lx_cols)[v];
+                        if (COLD(errors_out)) COLD(errors_out)[b * COLD(n) + v] = (uint8_t)e;
                     }
                     if (lm) atomicXor(&mc_lmask[slot], lm);
                     if (ew) atomicAdd(&mc_weight[slot], ew);
@@ -415,20 +429,20 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         if ((wmask >> j) & 1u) {
-                            const long long o = b * P.n + var[j];
-                            if (P.llr) P.llr[o] = val[j];
-                            if (P.hard) P.hard[o] = (uint8_t)(val[j] < 0.0);
+                            const long long o = b * COLD(n) + var[j];
+                            if (COLD(llr)) COLD(llr)[o] = val[j];
+                            if (COLD(hard)) COLD(hard)[o] = (uint8_t)(val[j] < 0.0);
                         }
                     }
-                    for (int i = c; i < P.n_iso; i += m) {
-                        const int v = P.iso_vars[i];
-                        const double pv = P.prior[v];
-                        if (P.llr) P.llr[b * P.n + v] = pv;
-                        if (P.hard) P.hard[b * P.n + v] = pv < 0.0;
+                    for (int i = c; i < COLD(n_iso); i += m) {
+                        const int v = COLD(iso_vars)[i];
+                        const double pv = COLD(prior)[v];
+                        if (COLD(llr)) COLD(llr)[b * COLD(n) + v] = pv;
+                        if (COLD(hard)) COLD(hard)[b * COLD(n) + v] = pv < 0.0;
                     }
                     if (c == 0) {
-                        if (P.converged) P.converged[b] = conv;
-                        if (P.iters) P.iters[b] = it;
+                        if (COLD(converged)) COLD(converged)[b] = conv;
+                        if (COLD(iters)) COLD(iters)[b] = it;
                     }
                 }
             }
@@ -455,11 +469,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             // final phase; everybody passed B1 since, so the accumulators are complete)
             if (mc_pending)
                 mc_classify(mc_lmask, mc_weight, mc_diff, mc_count, slot, mc_pending_conv,
-                            mc_pending_it, P.half_distance,
-                            P.fail_list != nullptr && !mc_pending_conv);
+                            mc_pending_it, COLD(half_distance),
+                            COLD(fail_list) != nullptr && !mc_pending_conv);
             for (int i = 0; i < NUM_COUNTERS; ++i)
                 if (mc_count[i])
-                    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i),
+                    atomicAdd(reinterpret_cast<unsigned long long*>(COLD(counters) + i),
                               (unsigned long long)mc_count[i]);
         }
     }
