@@ -37,7 +37,7 @@ def algorithmic_bytes(E, m, n, iters_total, B):
     return iters_total * 4 * E * 8 + B * (m + n + 8 * n + 5)
 
 
-def cpu_baseline(code, syndromes, prior, budget_s=12.0):
+def cpu_baseline(code, syndromes, prior, budget_s=15.0):
     """The CPU oracle (oracle/bp_oracle.c: a port of decoding/beliefPropagation.py:88-144),
     one host thread, forced 50 iterations, on a bounded sample of the same syndromes."""
     from oracle import oracle
@@ -196,7 +196,7 @@ def main():
             "converged_fraction": counts[0] / (world * B),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(code, syndromes[:4096].cpu().numpy(),
+            out["cpu_baseline"] = cpu_baseline(code, syndromes[:20000].cpu().numpy(),
                                                prior.cpu().numpy())
         print(json.dumps(out), flush=True)
     if world > 1:
