@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void bp_generic_kernel(const GenericParams P)
                     Q[e] = qn;
                 } else {
                     const double q = P.damping * qn + one_minus_damping * Q[e];
-                    Q[e] = __builtin_fmin(__builtin_fmax(q, -P.clip_llr), P.clip_llr);
+                    const double y = q < -P.clip_llr ? -P.clip_llr : q;     // np.clip, NaN stays NaN
+                    Q[e] = y > P.clip_llr ? P.clip_llr : y;
                 }
             }
             // ---- syndrome check (:137-139) -----------------------------------------------------

@@ -117,8 +117,15 @@ __device__ __forceinline__ ColdArgs cold_args()
 #define COLD(field) (cold_args()->field)
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi)
-{   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi): v_max_f64 + v_min_f64
+{   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi) for non-NaN x: v_max_f64 + v_min_f64
     return __builtin_fmin(__builtin_fmax(x, lo), hi);
+}
+
+__device__ __forceinline__ double clipd_nan(double x, double lo, double hi)
+{   // same, but a NaN stays a NaN as in np.clip (the damped variants can produce inf - inf when
+    // a check has a single edge: rework/decoding.py keeps iterating on NaNs there)
+    const double y = x < lo ? lo : x;
+    return y > hi ? hi : y;
 }
 
 // Classification of one finished trial by its slot leader (paperResults_GPU.py:127-144 without
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     Q[j] = qn;
                 } else {
                     const double q = P.damping * qn + one_minus_damping * Q[j];
-                    Q[j] = clipd(q, -P.clip_llr, P.clip_llr);
+                    Q[j] = clipd_nan(q, -P.clip_llr, P.clip_llr);
                 }
             }
             if (P.padded) {                                       // wave-uniform branch

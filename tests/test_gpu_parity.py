@@ -5,7 +5,7 @@ import pytest
 
 import golden_util
 from oracle import oracle
-from qldpc_amd import _lib, bp, codes
+from qldpc_amd import _lib, bp, codes, mc
 
 pytestmark = pytest.mark.gpu
 
@@ -191,3 +191,63 @@ def test_large_spacetime_matrix_vs_oracle():
     fast = conv & (iters <= 20)
     rel = np.abs(llr - o[3]) / np.maximum(np.abs(o[3]), 1e-300)
     assert fast.any() and rel[fast].max() <= 1e-5
+
+
+@pytest.mark.parametrize("name,B,variant,kw", [
+    ("[[144, 12, 12]]", 100_000, _lib.MIN_SUM, dict(alpha=0.8, damping=0.7, clip_llr=25.0)),   # config 3
+    ("[[288, 12, 18]]", 125_000, _lib.SUM_PRODUCT, {}),                                       # config 4 shard
+])
+def test_full_size_batches_properties(name, B, variant, kw):
+    """BASELINE.json batch sizes, checked through size-independent properties plus an oracle
+    comparison on a random subset."""
+    code = codes.load_code(name)
+    rng = np.random.default_rng(99)
+    p = 0.04
+    err = (rng.random((B, code.n)) < p).astype(np.uint8)
+    syn = (err.astype(np.float32) @ code.Hx.T.astype(np.float32) % 2).astype(np.uint8)
+    prior = mc.prior_of(p, code.n)
+    dec = bp.decoder_for(code.Hx)
+    hard, conv, iters, llr = dec.decode(syn, prior, 50, variant, **kw)
+    # (1) converged  <=>  H . hard == syndrome   (non-converged outputs must NOT satisfy it)
+    ok = ((hard.astype(np.float32) @ code.Hx.T.astype(np.float32)) % 2 == syn).all(1)
+    assert np.array_equal(ok, conv)
+    # (2) iteration index range and hard decision == sign of the LLR
+    assert iters.min() >= 0 and iters.max() <= 49 and (iters[~conv] == 49).all()
+    assert np.array_equal(hard, (llr < 0).astype(np.uint8))
+    # (3) batch order does not matter, and a second run gives the same bits
+    perm = rng.permutation(B)
+    h2, c2, i2, l2 = dec.decode(syn[perm], prior, 50, variant, **kw)
+    assert np.array_equal(h2, hard[perm]) and np.array_equal(i2, iters[perm])
+    assert np.array_equal(l2, llr[perm])
+    # (4) the all-zero syndrome rows converge at iteration 0 with hard = 0
+    z = ~syn.any(1)
+    assert conv[z].all() and (iters[z] == 0).all() and not hard[z].any()
+    # (5) oracle on a random subset
+    sub = rng.choice(B, 1500, replace=False)
+    o = oracle.decode_batch(code.Hx, syn[sub], prior, 50, variant, **kw)
+    assert np.array_equal(hard[sub], o[0]) and np.array_equal(conv[sub], o[1])
+    assert np.array_equal(iters[sub], o[2])
+    print(f"{name}: B={B}, converged {conv.mean():.4f}, mean iterations {iters.mean() + 1:.2f}")
+
+
+def test_random_small_matrices_general_kernel_vs_oracle():
+    """Fuzz: random sparse matrices of arbitrary shape (empty rows / columns, wide rows) through
+    whichever kernel fits, against the oracle."""
+    rng = np.random.default_rng(2024)
+    for trial in range(25):
+        m, n = int(rng.integers(1, 40)), int(rng.integers(2, 80))
+        H = (rng.random((m, n)) < rng.uniform(0.03, 0.3)).astype(np.int64)
+        for r in np.flatnonzero(H.sum(1) == 1):     # a single-edge check makes min-sum emit inf
+            H[r, rng.choice(np.flatnonzero(H[r] == 0))] = 1   # (min2 of an empty set) -> NaN soup
+        pv = rng.uniform(0.01, 0.3, n)
+        err = (rng.random((40, n)) < pv).astype(np.int64)
+        syn = (err @ H.T % 2).astype(np.uint8)
+        prior = np.log((1 - pv) / pv)
+        dec = bp.decoder_for(H)
+        for variant, kw in ((_lib.SUM_PRODUCT, {}), (_lib.MIN_SUM, dict(alpha=0.75, damping=0.8, clip_llr=30.0))):
+            hard, conv, iters, llr = dec.decode(syn, prior, 25, variant, **kw)
+            o = oracle.decode_batch(H, syn, prior, 25, variant, **kw)
+            assert np.array_equal(conv, o[1]), (trial, m, n)
+            assert np.array_equal(iters, o[2]) and np.array_equal(hard, o[0])
+            fin = np.isfinite(o[3]) & conv[:, None] & (iters <= 10)[:, None]
+            assert np.allclose(llr[fin], o[3][fin], rtol=1e-6, atol=1e-9)
