@@ -6,12 +6,14 @@ entry point raises (``QbpError``) instead of computing something else.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqbp.so")
+LIB_PATH = os.environ.get("QBP_LIB_PATH") or os.path.join(_HERE, "csrc", "libqbp.so")   # override: experiments
 
 SUM_PRODUCT, DAMPED_SP, MIN_SUM = 0, 1, 2
 FLAG_FORCE_FULL = 1
@@ -62,6 +64,28 @@ class QbpError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so.7``
+    (plus a matching HSA runtime); the system ROCm has a library of the same SONAME.  Whichever is
+    loaded first serves both libqbp and torch -- and torch cannot initialise on the system copy
+    ("No HIP GPUs are available").  So if torch is installed (it need not be imported, and is not
+    imported here), load its copy first; libqbp's DT_NEEDED entry then resolves to it."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libqbp.so (built by ``__graft_entry__.build()`` / ``make -C qldpc_amd/csrc``)."""
     global _lib
@@ -69,6 +93,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise QbpError(f"{LIB_PATH} is missing: build it with `python -c 'import "
                            f"__graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+        _preload_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

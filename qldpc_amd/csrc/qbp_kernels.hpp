@@ -156,6 +156,7 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
 }
 
 // LDS carve (in units of 8 bytes after the message area):
+//   [DC][m] priors of the edges' variables (+inf for padding edges)
 //   [S]  next work index per slot
 //   [S]  MC logical-mask accumulator
 //   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
@@ -175,7 +176,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 
     double* const Rs = smem + (size_t)sl * P.slot_stride;
     const int zoff = DC * m;
-    long long* const next_work = reinterpret_cast<long long*>(smem + (size_t)S * P.slot_stride);
+    // priors of this check's variables, [edge j][check c], shared by all slots (an LDS read per
+    // use instead of 12 VGPRs per lane for the whole kernel)
+    double* const pri_lds = smem + (size_t)S * P.slot_stride;
+    long long* const next_work = reinterpret_cast<long long*>(pri_lds + DC * m);
     unsigned long long* const mc_lmask = reinterpret_cast<unsigned long long*>(next_work + S);
     int* const words = reinterpret_cast<int*>(mc_lmask + S);
     int* const flag0 = words;            // [2][S]
@@ -185,14 +189,14 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     int* const mc_count = words + 4 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
 
     // ---- per-lane static tables (registers for the whole kernel) ---------------------------
-    int var[DC];
-    double pri[DC];
     unsigned short nbr[DC][DV];
     unsigned wmask = 0;
+    unsigned vmask = 0;            // bit j: edge j of this check exists (not padding)
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
-        var[j] = lane_valid ? P.tab_var[j * m + c] : -1;
-        pri[j] = var[j] >= 0 ? P.prior[var[j]] : __builtin_inf();
+        const int v = lane_valid ? P.tab_var[j * m + c] : -1;
+        vmask |= (v >= 0 ? 1u : 0u) << j;
+        if (slot == 0) pri_lds[j * m + c] = v >= 0 ? P.prior[v] : __builtin_inf();
 #pragma unroll
         for (int k = 0; k < DV; ++k)
             nbr[j][k] = lane_valid ? P.tab_nbr[(j * DV + k) * m + c] : (unsigned short)zoff;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         it = 0;
         frozen = false;
 #pragma unroll
-        for (int j = 0; j < DC; ++j) Q[j] = pri[j];      // Q = where(mask, initialBelief, 0)
+        for (int j = 0; j < DC; ++j) Q[j] = pri_lds[j * m + c];   // Q = where(mask, initialBelief, 0)
         if constexpr (MC) {
             const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
             ebits = 0;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 double s = rr[j][0];
 #pragma unroll
                 for (int k = 1; k < DV; ++k) s = s + rr[j][k];   // ascending check order
-                val[j] = s + pri[j];
+                val[j] = s + pri_lds[j * m + c];
                 odd ^= val[j] < 0.0;                              // hard decision: values < 0
                 const double qn = val[j] - R[j];
                 if constexpr (VARIANT == 0) {
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             if (P.padded) {                                       // wave-uniform branch
 #pragma unroll
                 for (int j = 0; j < DC; ++j)
-                    if (var[j] < 0) Q[j] = __builtin_inf();       // padding stays neutral
+                    if (!((vmask >> j) & 1u)) Q[j] = __builtin_inf();   // padding stays neutral
             }
             if (odd) flag0[(phase & 1u) * S + slot] = 1;          // this check is unsatisfied
         }
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
                         for (int j = 0; j < DC; ++j) {
                             if ((wmask >> j) & 1u) {
-                                const long long o = b * COLD(n) + var[j];
+                                const long long o = b * COLD(n) + P.tab_var[j * m + c];
                                 COLD(fail_llr)[o] = val[j];
                                 COLD(fail_hard)[o] = (uint8_t)(val[j] < 0.0);
                                 COLD(fail_err)[o] = (uint8_t)((ebits >> j) & 1u);
@@ -414,8 +418,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                             const unsigned res = (val[j] < 0.0 ? 1u : 0u) ^ e;
                             ew += (int)e;
                             df |= res;
-                            if (res) lm ^= COLD(lx_cols)[var[j]];
-                            if (COLD(errors_out)) COLD(errors_out)[b * COLD(n) + var[j]] = (uint8_t)e;
+                            const int v = P.tab_var[j * m + c];
+                            if (res) lm ^= COLD(lx_cols)[v];
+                            if (COLD(errors_out)) COLD(errors_out)[b * COLD(n) + v] = (uint8_t)e;
                         }
                     }
                     for (int i = c; i < COLD(n_iso); i += m) {
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         if ((wmask >> j) & 1u) {
-                            const long long o = b * COLD(n) + var[j];
+                            const long long o = b * COLD(n) + P.tab_var[j * m + c];
                             if (COLD(llr)) COLD(llr)[o] = val[j];
                             if (COLD(hard)) COLD(hard)[o] = (uint8_t)(val[j] < 0.0);
                         }
