@@ -168,7 +168,7 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
     cfg->slot_stride = DC_FUSED * m + 2;
     size_t lds = ((size_t)S * cfg->slot_stride + (size_t)DC_FUSED * m + 2 * (size_t)S) * 8 +
-                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS) * 4;
+                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)DC_FUSED * m) * 4;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
     cfg->lds_bytes = (int)lds;

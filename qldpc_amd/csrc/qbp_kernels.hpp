@@ -160,7 +160,7 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
 //   [S]  next work index per slot
 //   [S]  MC logical-mask accumulator
 //   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
-//   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only)
+//   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only), var_lds[DC][m]
 template <int DC, int DV, int VARIANT, bool MC, bool FORCE_FULL, int MAX_THREADS, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kernel(const FusedParams P)
 {
@@ -180,6 +180,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // use instead of 12 VGPRs per lane for the whole kernel)
     double* const pri_lds = smem + (size_t)S * P.slot_stride;
     long long* const next_work = reinterpret_cast<long long*>(pri_lds + DC * m);
+    // (the variable indices of the edges, needed only when a syndrome is emitted, sit behind the
+    // 32-bit words below: var_lds[DC][m])
     unsigned long long* const mc_lmask = reinterpret_cast<unsigned long long*>(next_work + S);
     int* const words = reinterpret_cast<int*>(mc_lmask + S);
     int* const flag0 = words;            // [2][S]
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     int* const mc_diff = words + 3 * S;
     int* const active_count = words + 4 * S;
     int* const mc_count = words + 4 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
+    int* const var_lds = words + 4 * S + 1 + S * NUM_COUNTERS;     // [DC][m], -1 = padding
 
     // ---- per-lane static tables (registers for the whole kernel) ---------------------------
     unsigned short nbr[DC][DV];
@@ -196,7 +199,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     for (int j = 0; j < DC; ++j) {
         const int v = lane_valid ? P.tab_var[j * m + c] : -1;
         vmask |= (v >= 0 ? 1u : 0u) << j;
-        if (slot == 0) pri_lds[j * m + c] = v >= 0 ? P.prior[v] : __builtin_inf();
+        if (slot == 0) {
+            pri_lds[j * m + c] = v >= 0 ? P.prior[v] : __builtin_inf();
+            var_lds[j * m + c] = v;
+        }
 #pragma unroll
         for (int k = 0; k < DV; ++k)
             nbr[j][k] = lane_valid ? P.tab_nbr[(j * DV + k) * m + c] : (unsigned short)zoff;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             ebits = 0;
 #pragma unroll 1
             for (int j = 0; j < DC; ++j) {        // once per trial: keep it out of the registers
-                const int v = P.tab_var[j * m + c];
+                const int v = var_lds[j * m + c];
                 if (v >= 0) ebits |= mc_error_bit(trial, v, COLD(draws), COLD(seed), COLD(threshold)) << j;
             }
             sbit = __builtin_popcount(ebits) & 1u;       // syndrome = H e mod 2
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
                         for (int j = 0; j < DC; ++j) {
                             if ((wmask >> j) & 1u) {
-                                const long long o = b * COLD(n) + P.tab_var[j * m + c];
+                                const long long o = b * COLD(n) + var_lds[j * m + c];
                                 COLD(fail_llr)[o] = val[j];
                                 COLD(fail_hard)[o] = (uint8_t)(val[j] < 0.0);
                                 COLD(fail_err)[o] = (uint8_t)((ebits >> j) & 1u);
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                             const unsigned res = (val[j] < 0.0 ? 1u : 0u) ^ e;
                             ew += (int)e;
                             df |= res;
-                            const int v = P.tab_var[j * m + c];
+                            const int v = var_lds[j * m + c];
                             if (res) lm ^= COLD(lx_cols)[v];
                             if (COLD(errors_out)) COLD(errors_out)[b * COLD(n) + v] = (uint8_t)e;
                         }
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         if ((wmask >> j) & 1u) {
-                            const long long o = b * COLD(n) + P.tab_var[j * m + c];
+                            const long long o = b * COLD(n) + var_lds[j * m + c];
                             if (COLD(llr)) COLD(llr)[o] = val[j];
                             if (COLD(hard)) COLD(hard)[o] = (uint8_t)(val[j] < 0.0);
                         }
