@@ -126,11 +126,15 @@ class Decoder:
         self.device = int(device)
 
     def close(self):
-        if getattr(self, "_h", None):
-            load().qbp_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.qbp_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:                      # at interpreter shutdown module globals may already be gone
+            self.close()
+        except Exception:
+            pass
 
     def info(self, what):
         return int(load().qbp_get_info(self._h, INFO[what]))
