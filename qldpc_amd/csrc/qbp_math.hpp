@@ -12,8 +12,9 @@
 //     an 11-term polynomial for p = expm1(r), numerator and denominator formed by one fma
 //     each around the exact constants 1 -+ 2^k (no cancellation for small |q|: k = 0 gives -p),
 //   * 2 atanh(y) = log((1+y)/(1-y)) = e ln2 + 2 atanh(s), s = (N - 2^e D) / (N + 2^e D),
-//     N = 1 + |y|, D = 1 - |y|: ONE division instead of the two of log1p(2y/(1-y)), and
-//     s == |y| exactly when e == 0 (small messages keep full relative accuracy).
+//     N = 1 + |y|, D = 1 - |y|: ONE division instead of the two of log1p(2y/(1-y)); numerator
+//     and denominator are single fmas of |y| with exact coefficients 1 -+ 2^e, and s == |y|
+//     exactly when e == 0 (small messages keep full relative accuracy).
 // Coefficients: tools/fit_math_coeffs.py (mpmath near-minimax fits).
 //
 // The header also compiles on the host (plain C++), where the reciprocal seed is 1.0 / b:
@@ -130,27 +131,31 @@ QBP_HD double tanh_half(double q)
 }
 
 // 2 * atanh(y) for |y| < 1 (the caller has clipped to |y| <= 0.9999999).
+//   w = (1 + a) / (1 - a), a = |y|;  pick e with w 2^-e in [1/sqrt2, sqrt2);
+//   log w = e ln2 + 2 atanh(s),  s = ((1 + a) - 2^e (1 - a)) / ((1 + a) + 2^e (1 - a)).
+// Numerator and denominator are linear in a with EXACT coefficients 1 -+ 2^e, so each is one
+// fma of the true value (no rounding of 1 + a or 1 - a enters, and for e = 0 they are exactly 2a
+// and 2: s == a, small messages keep full relative accuracy).  e depends on D = 1 - a only:
+// w = 2 / D - 1, and the two range tests below are N >= sqrt2 Dm and N sqrt2 < Dm written with
+// N = 2 - D, where Dm = D 2^e0 in [1, 2).
 QBP_HD double atanh2(double y)
 {
     constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;
+    constexpr double TWO_SQRT2 = 0x1.6a09e667f3bcdp+1;
     constexpr double LN2_HI = 0x1.62e42f8000000p-1;
     constexpr double LN2_LO = 0x1.be8e7bcd5e4f2p-27;
     const double a = __builtin_fabs(y);
-    const double N = 1.0 + a;                     // in [1, 2)
-    const double D = 1.0 - a;                     // in (0, 1]
-    const double N_lo = a - (N - 1.0);            // exact rounding error of N  (1 >= a)
-    const double D_lo = (1.0 - D) - a;            // exact rounding error of D
-    // e: (N / D) * 2^-e in [1/sqrt2, sqrt2)
-    const int e0 = 1 - frexp_exp_pos(D);          // D * 2^e0 in [1, 2)   (D >= 1e-7: normal)
-    const double Dm = scale2(D, e0);
+    const double D = 1.0 - a;                      // in [1e-7, 1]: normal
+    const int e0 = 1 - frexp_exp_pos(D);
+    const double Dm = scale2(D, e0);               // D 2^e0 in [1, 2)
     int e = e0;
-    e += (N >= SQRT2 * Dm) ? 1 : 0;
-    e -= (N * SQRT2 < Dm) ? 1 : 0;
-    const double Ds = scale2(D, e);
-    const double Ds_lo = scale2(D_lo, e);         // D_lo == 0 -> ~2^-1000, negligible next to N_lo
-    const double num = (N - Ds) + (N_lo - Ds_lo); // e == 0: (2a) + 0 exactly
-    const double den = N + Ds;                    // e == 0: 2 exactly
-    const double s = div_nr(num, den);            // |s| <= 0.1716
+    e += (__builtin_fma(Dm, SQRT2, D) <= 2.0) ? 1 : 0;
+    e -= (__builtin_fma(D, SQRT2, Dm) > TWO_SQRT2) ? 1 : 0;
+    const double pw = pow2i(e);                    // e in [0, 25]
+    const double cp = 1.0 + pw, cm = 1.0 - pw;     // exact
+    const double num = __builtin_fma(a, cp, cm);   // (1 + a) - 2^e (1 - a)
+    const double den = __builtin_fma(a, cm, cp);   // (1 + a) + 2^e (1 - a)
+    const double s = div_nr(num, den);             // |s| <= 0.1716
     const double z = s * s;
     double L = 0x1.2c7878482df85p-3;
     L = __builtin_fma(L, z, 0x1.39e6974a2f9f4p-3);
