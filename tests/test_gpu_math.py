@@ -32,7 +32,7 @@ def test_device_math_ulp():
     w = _ulps(got[fin], xs[fin], lambda v: mp.tanh(v / 2))
     assert got[-2] == 1.0 and got[-1] == -1.0
     print(f"device tanh_half worst {w:.3f} ulp")
-    assert w <= 2.0
+    assert w <= 2.5
     C0 = 0.9999999
     ys = np.clip(np.concatenate([rng.uniform(-C0, C0, 4000),
                                  rng.choice([-1, 1], 2000) * (1 - 10.0 ** rng.uniform(-7, 0, 2000)),

