@@ -174,6 +174,18 @@ def main():
                 traffic = json.load(open(tf)).get("bytes_per_launch_forced50")
             except Exception:
                 traffic = None
+        valu = None
+        pf = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pf):
+            try:
+                dd = json.load(open(pf))["derived"]
+                valu = {"note": "the physically binding resource (FP64 vector ALU), from the PMC passes in "
+                                "profiles/r01_pmc_summary.json -- not measured by this run",
+                        "valu_busy_fraction": dd["valu_busy_fraction"],
+                        "valu_insts_per_syndrome_iteration": dd["valu_insts_per_syndrome_iteration"],
+                        "shader_clock_GHz": dd["shader_clock_GHz"]}
+            except Exception:
+                valu = None
         out = {
             "metric": "syndromes/sec at 50 BP iters, [[288,12,18]] code",
             "value": value, "unit": "syndromes/s", "n_gpus": world, "steps": args.steps,
@@ -193,6 +205,7 @@ def main():
                          "note": "effective bandwidth: messages stay in LDS/registers, physical HBM "
                                  "traffic is only syndrome/LLR I/O; the physical limiter is FP64 VALU"},
             "early_exit": early,
+            "valu_f64": valu,
             "converged_fraction": counts[0] / (world * B),
         }
         if not args.no_cpu_baseline and world == 1:
