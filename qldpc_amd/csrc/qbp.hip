@@ -168,7 +168,8 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
     cfg->slot_stride = DC_FUSED * m + 2;
     size_t lds = ((size_t)S * cfg->slot_stride + (size_t)DC_FUSED * m + 2 * (size_t)S) * 8 +
-                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)DC_FUSED * m) * 4;
+                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)DC_FUSED * m) * 4 +
+                 (size_t)S * (((size_t)h->n + 3) / 4) * 4;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
     cfg->lds_bytes = (int)lds;
@@ -207,6 +208,7 @@ void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg)
     P.m = h->m; P.n = h->n;
     P.S = cfg.S; P.slot_stride = cfg.slot_stride;
     P.padded = h->padded ? 1 : 0;
+    P.n_words4 = (h->n + 3) / 4;
     P.tab_var = h->d_tab_var.p; P.tab_nbr = h->d_tab_nbr.p; P.tab_writer = h->d_tab_writer.p;
     P.iso_vars = h->d_iso.p; P.n_iso = h->n_iso;
     P.work_counter = h->d_work_counter.p;

@@ -43,6 +43,7 @@ struct FusedParams {
     int max_iter;
     unsigned flags;
     int padded;                 // some row has fewer than DC edges (irregular H)
+    int n_words4;               // ceil(n / 4)
     double alpha, damping, clip_llr;
     // outputs (decode mode; may be null)
     uint8_t* hard;
@@ -88,20 +89,6 @@ __device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsign
     }
 }
 
-// Error bit of qubit v in trial `trial` (specification: oracle/bp_oracle.c, oracle_mc_errors).
-__device__ __forceinline__ unsigned mc_error_bit(unsigned long long trial, int v, int draws,
-                                                 unsigned long long seed, unsigned thr)
-{
-    unsigned bit = 0;
-    for (int d = 0; d < draws; ++d) {
-        unsigned c[4] = {(unsigned)trial, (unsigned)(trial >> 32), (unsigned)(v >> 2), (unsigned)d};
-        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
-        const unsigned w = (v & 3) == 0 ? c[0] : (v & 3) == 1 ? c[1] : (v & 3) == 2 ? c[2] : c[3];
-        bit ^= (w < thr) ? 1u : 0u;
-    }
-    return bit;
-}
-
 // Rarely used launch parameters (output pointers, Monte-Carlo settings, ...) are re-read from the
 // kernel-argument segment where they are needed instead of being kept in SGPRs for the whole
 // kernel: the hot loop already needs ~60 SGPRs for FP64 constants, and every SGPR the compiler
@@ -115,6 +102,22 @@ __device__ __forceinline__ ColdArgs cold_args()
     return p;
 }
 #define COLD(field) (cold_args()->field)
+
+// Error bits of qubits 4g .. 4g+3 of trial `trial` as bytes (0/1) packed in a u32: one Philox
+// evaluation per draw serves four qubits (specification: oracle/bp_oracle.c, oracle_mc_errors:
+// counter = (trial lo, trial hi, qubit / 4, draw), word qubit % 4, bit = word < floor(p 2^32)).
+__device__ __forceinline__ unsigned mc_error_quad(unsigned long long trial, int g, int draws,
+                                                  unsigned long long seed, unsigned thr)
+{
+    unsigned bytes = 0;
+    for (int d = 0; d < draws; ++d) {
+        unsigned c[4] = {(unsigned)trial, (unsigned)(trial >> 32), (unsigned)g, (unsigned)d};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        bytes ^= (c[0] < thr ? 1u : 0u) | (c[1] < thr ? 0x100u : 0u) | (c[2] < thr ? 0x10000u : 0u) |
+                 (c[3] < thr ? 0x1000000u : 0u);
+    }
+    return bytes;
+}
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi)
 {   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi) for non-NaN x: v_max_f64 + v_min_f64
@@ -160,7 +163,7 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
 //   [S]  next work index per slot
 //   [S]  MC logical-mask accumulator
 //   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
-//   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only), var_lds[DC][m]
+//   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only), var_lds[DC][m], err_lds[S][n4] bytes (MC)
 template <int DC, int DV, int VARIANT, bool MC, bool FORCE_FULL, int MAX_THREADS, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kernel(const FusedParams P)
 {
@@ -190,6 +193,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     int* const active_count = words + 4 * S;
     int* const mc_count = words + 4 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
     int* const var_lds = words + 4 * S + 1 + S * NUM_COUNTERS;     // [DC][m], -1 = padding
+    // Monte-Carlo mode: sampled error bytes of the slot's current trial, [S][n4] (n4 = n rounded
+    // up to a multiple of 4), written by the slot's first ceil(n/4) lanes one barrier before use
+    const int n4 = (P.n_words4) * 4;
+    unsigned char* const err_lds = reinterpret_cast<unsigned char*>(var_lds + DC * m) + (size_t)sl * n4;
 
     // ---- per-lane static tables (registers for the whole kernel) ---------------------------
     unsigned short nbr[DC][DV];
@@ -256,12 +263,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
         for (int j = 0; j < DC; ++j) Q[j] = pri_lds[j * m + c];   // Q = where(mask, initialBelief, 0)
         if constexpr (MC) {
-            const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
             ebits = 0;
-#pragma unroll 1
-            for (int j = 0; j < DC; ++j) {        // once per trial: keep it out of the registers
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
                 const int v = var_lds[j * m + c];
-                if (v >= 0) ebits |= mc_error_bit(trial, v, COLD(draws), COLD(seed), COLD(threshold)) << j;
+                if (v >= 0) ebits |= (unsigned)err_lds[v] << j;
             }
             sbit = __builtin_popcount(ebits) & 1u;       // syndrome = H e mod 2
         } else {
@@ -277,6 +283,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     int mc_pending_conv = 0, mc_pending_it = 0;
 
     for (unsigned phase = 0;; ++phase) {
+        if constexpr (MC) {
+            // Sample the errors of a trial that starts in this phase: one Philox evaluation per
+            // four qubits, by the first ceil(n/4) lanes of the slot; the extra barrier (Monte-Carlo
+            // builds only) orders the bytes before the check lanes gather them.
+            if (need_start) {
+                const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
+                for (int g = c; g < P.n_words4; g += m)
+                    reinterpret_cast<unsigned*>(err_lds)[g] =
+                        mc_error_quad(trial, g, COLD(draws), COLD(seed), COLD(threshold));
+            }
+            __syncthreads();                                      // B0
+        }
         if (need_start) { start_syndrome(); need_start = false; }
         // ================= check step =======================================================
         if (active) {
@@ -392,7 +410,6 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             const bool last = it == max_iter - 1;
             if (!frozen && (conv || last)) {
                 if constexpr (MC) {
-                    const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
                     if (COLD(fail_list) != nullptr && !conv) {
                         // BP failed: leave the trial to the OSD kernel (record indexed by b)
                         COLD(fail_syn)[b * m + c] = (uint8_t)sbit;
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                             const long long o = b * COLD(n) + v;
                             COLD(fail_llr)[o] = COLD(prior)[v];
                             COLD(fail_hard)[o] = (uint8_t)(COLD(prior)[v] < 0.0);
-                            COLD(fail_err)[o] = (uint8_t)mc_error_bit(trial, v, COLD(draws), COLD(seed), COLD(threshold));
+                            COLD(fail_err)[o] = err_lds[v];
                         }
                         if (c == 0) COLD(fail_list)[atomicAdd(COLD(fail_count), 1ull)] = b;
                     } else {
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     }
                     for (int i = c; i < COLD(n_iso); i += m) {
                         const int v = COLD(iso_vars)[i];
-                        const unsigned e = mc_error_bit(trial, v, COLD(draws), COLD(seed), COLD(threshold));
+                        const unsigned e = err_lds[v];
                         const unsigned res = (COLD(prior)[v] < 0.0 ? 1u : 0u) ^ e;
                         ew += (int)e;
                         df |= res;
