@@ -44,6 +44,8 @@ def lib():
             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
             C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint32,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_bp_decode_batch_mt.restype = C.c_int
+        L.oracle_bp_decode_batch_mt.argtypes = L.oracle_bp_decode_batch.argtypes + [C.c_int32]
         L.oracle_mc_errors.restype = None
         L.oracle_mc_errors.argtypes = [C.c_int32, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                        C.c_int64, C.c_void_p]
@@ -69,8 +71,9 @@ def csr_of(H):
 
 
 def decode_batch(H, syndromes, prior, max_iter=50, variant=0, alpha=1.0, damping=1.0,
-                 clip_llr=20.0, flags=0):
-    """Returns ``(hard u8[B,n], converged bool[B], iters i32[B], llr f64[B,n])``."""
+                 clip_llr=20.0, flags=0, threads=1):
+    """Returns ``(hard u8[B,n], converged bool[B], iters i32[B], llr f64[B,n])``.
+    ``threads`` > 1 spreads the (independent) syndromes over host threads (CPU baseline only)."""
     row_ptr, col_idx, m, n = csr_of(H)
     syn = np.ascontiguousarray(np.atleast_2d(np.asarray(syndromes)).astype(np.uint8))
     B = syn.shape[0]
@@ -81,10 +84,10 @@ def decode_batch(H, syndromes, prior, max_iter=50, variant=0, alpha=1.0, damping
     conv = np.zeros(B, np.uint8)
     iters = np.zeros(B, np.int32)
     llr = np.zeros((B, n), np.float64)
-    rc = lib().oracle_bp_decode_batch(
+    rc = lib().oracle_bp_decode_batch_mt(
         m, n, row_ptr.ctypes.data, col_idx.ctypes.data, syn.ctypes.data, pr.ctypes.data, B,
         int(max_iter), int(variant), float(alpha), float(damping), float(clip_llr), int(flags),
-        hard.ctypes.data, conv.ctypes.data, iters.ctypes.data, llr.ctypes.data)
+        hard.ctypes.data, conv.ctypes.data, iters.ctypes.data, llr.ctypes.data, int(threads))
     if rc != 0:
         raise ValueError(f"oracle_bp_decode_batch failed: {rc}")
     return hard, conv.astype(bool), iters, llr
