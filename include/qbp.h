@@ -151,7 +151,6 @@ int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
 enum {
     QBP_OPT_SLOTS_PER_BLOCK = 1, /* syndromes decoded concurrently by one workgroup (0 = auto) */
     QBP_OPT_BLOCKS_PER_CU = 2,   /* persistent workgroups per CU (0 = auto)                    */
-    QBP_OPT_REG_VARIANT = 3,     /* register-budget build of the kernel (0 = auto; tuning)     */
     QBP_OPT_FORCE_GENERIC = 4,   /* 1 = use the general-H kernel even where the on-chip one fits */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
     QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 fused on-chip, 2 generic */

@@ -75,12 +75,12 @@ struct qbp_handle {
     int n_iso = 0;
     DevBuf<unsigned long long> d_work_counter;
     // options
-    int opt_slots = 0, opt_blocks_per_cu = 0, opt_reg_variant = 0;
+    int opt_slots = 0, opt_blocks_per_cu = 0;
     // last launch configuration (introspection)
     int last_threads = 0, last_lds = 0, last_grid = 0;
     // scratch for the host-pointer entry points
     hipStream_t stream = nullptr;
-    DevBuf<uint8_t> d_syn, d_hard, d_conv, d_lx_bytes;
+    DevBuf<uint8_t> d_syn, d_hard, d_conv;
     DevBuf<int32_t> d_iters;
     DevBuf<double> d_llr, d_prior, d_mathx, d_mathy;
     DevBuf<unsigned long long> d_lx_cols;
@@ -132,22 +132,14 @@ hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t st
 }
 
 template <bool MC>
-hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s,
-                          int reg_variant)
+hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s)
 {
-    // Default build: __launch_bounds__(1024) = 128-VGPR budget = 4 wavefronts per SIMD, the fastest
-    // measured (profiles/r01_tune.txt).  The other register budgets exist for tuning runs only.
+    // __launch_bounds__(1024): 128-VGPR budget = 4 wavefronts per SIMD, the fastest geometry
+    // measured (profiles/r01_tune.txt; builds with 3 or 5 waves per SIMD were slower).
     switch (variant) {
-        case QBP_SUM_PRODUCT:
-            if constexpr (!MC) {
-                if (reg_variant == 1 && cfg.threads <= 640) return launch_one<0, MC, 640, 1>(P, cfg, s);
-                if (reg_variant == 3 && cfg.threads <= 640) return launch_one<0, MC, 640, 5>(P, cfg, s);
-            }
-            return launch_one<0, MC, 1024>(P, cfg, s);
-        case QBP_DAMPED_SP:
-            return launch_one<1, MC, 1024>(P, cfg, s);
-        default:
-            return launch_one<2, MC, 1024>(P, cfg, s);
+        case QBP_SUM_PRODUCT: return launch_one<0, MC, 1024>(P, cfg, s);
+        case QBP_DAMPED_SP:   return launch_one<1, MC, 1024>(P, cfg, s);
+        default:              return launch_one<2, MC, 1024>(P, cfg, s);
     }
 }
 
@@ -350,7 +342,7 @@ void qbp_destroy(qbp_handle* h)
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     h->d_tab_var.release(); h->d_tab_nbr.release(); h->d_tab_writer.release(); h->d_iso.release();
     h->d_work_counter.release(); h->d_syn.release(); h->d_hard.release(); h->d_conv.release();
-    h->d_lx_bytes.release(); h->d_iters.release(); h->d_llr.release(); h->d_prior.release();
+    h->d_iters.release(); h->d_llr.release(); h->d_prior.release();
     h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
     h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
     h->d_wsV.release(); h->d_wsC.release();
@@ -416,7 +408,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     P.alpha = alpha; P.damping = damping; P.clip_llr = clip_llr;
     P.hard = d_hard; P.converged = d_converged; P.iters = d_iters; P.llr = d_llr;
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<false>(variant, P, cfg, s, h->opt_reg_variant));
+    HIP_TRY(launch_variant<false>(variant, P, cfg, s));
     return QBP_OK;
 }
 
@@ -606,7 +598,7 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
         P.fail_hard = h->d_fail_hard.p; P.fail_err = h->d_fail_err.p;
     }
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<true>(variant, P, cfg, s, h->opt_reg_variant));
+    HIP_TRY(launch_variant<true>(variant, P, cfg, s));
     if (osd) {
         // second kernel: OSD-0 + classification of the trials BP left unconverged; their number is
         // read from device memory by the kernel itself (no host round trip)
@@ -676,7 +668,7 @@ int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
     P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = 0;
     P.counters = h->d_counters.p; P.errors_out = h->d_hard.p;
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<true>(QBP_MIN_SUM, P, cfg, s, 0));
+    HIP_TRY(launch_variant<true>(QBP_MIN_SUM, P, cfg, s));
     HIP_TRY(hipMemcpyAsync(errors, h->d_hard.p, (size_t)T * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
@@ -694,9 +686,6 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
             h->opt_blocks_per_cu = (int)value; return QBP_OK;
         case QBP_OPT_FORCE_GENERIC:
             h->opt_force_generic = value != 0; return QBP_OK;
-        case QBP_OPT_REG_VARIANT:
-            if (value < 0 || value > 4) return fail(QBP_E_INVALID, "register variant out of range");
-            h->opt_reg_variant = (int)value; return QBP_OK;
         default: return fail(QBP_E_INVALID, "unknown option %d", option);
     }
 }

@@ -251,3 +251,13 @@ def test_random_small_matrices_general_kernel_vs_oracle():
             assert np.array_equal(iters, o[2]) and np.array_equal(hard, o[0])
             fin = np.isfinite(o[3]) & conv[:, None] & (iters <= 10)[:, None]
             assert np.allclose(llr[fin], o[3][fin], rtol=1e-6, atol=1e-9)
+
+
+def test_c_example_runs_on_gpu(tmp_path):
+    """The plain-C program of examples/ (no Python, no torch) reproduces main.py's known answer."""
+    import subprocess
+    from test_host_cpu import _build_c_example
+    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "converged 1 at iteration 0: 0010000" in r.stdout
+    assert "1.06635143 1.06635143 -0.06452172 3.32809773 2.19722458 2.19722458 1.06635143" in r.stdout

@@ -117,3 +117,23 @@ def test_results_writer_schema(tmp_path):
     assert loaded["[[72, 12, 6]]"]["BPs_fault"] == [0, 0]
     back, meta = paper_results.load_results(path)
     assert back == loaded and meta["physicalErrorRates"] == [0.05, 0.01]
+
+
+def _build_c_example(tmp_path):
+    exe = str(tmp_path / "decode_steane")
+    csrc = os.path.join(ROOT, "qldpc_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "decode_steane.c"), "-L", csrc, "-lqbp", "-lm",
+                           f"-Wl,-rpath,{csrc}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_library_links_from_c(lib, tmp_path):
+    """include/qbp.h must be usable from C (no C++, no torch types): build examples/decode_steane.c
+    with gcc -std=c99 -pedantic -Werror and link it against libqbp.so."""
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if os.path.exists("/dev/kfd"):
+        assert r.returncode == 0 and "converged 1 at iteration 0: 0010000" in r.stdout
+    else:
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr

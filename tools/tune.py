@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep launch geometry of the fused kernel on the GPU box: slots per workgroup x workgroups per
-CU x register-budget build, [[288,12,18]] forced 50 iterations.  Prints one line per config."""
+CU, [[288,12,18]] forced 50 iterations.  Prints one line per config."""
 import argparse
 import itertools
 import json
@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--p", type=float, default=0.01)
     ap.add_argument("--slots", type=int, nargs="+", default=[1, 2, 3, 4, 5, 6, 7])
     ap.add_argument("--blocks", type=int, nargs="+", default=[1, 2, 3, 4])
-    ap.add_argument("--regs", type=int, nargs="+", default=[0, 2, 3])
     ap.add_argument("--early-exit", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
@@ -41,15 +40,12 @@ def main():
     stream = torch.cuda.current_stream(dev)
     flags = 0 if args.early_exit else _lib.FLAG_FORCE_FULL
     results = []
-    for S, blocks, regs in itertools.product(args.slots, args.blocks, args.regs):
+    for S, blocks in itertools.product(args.slots, args.blocks):
         if S * m > 1024:
             continue
         threads = ((S * m + 63) // 64) * 64
-        if regs in (3, 4) and threads > 640:
-            continue
         dec.set_option(_lib.OPT_SLOTS_PER_BLOCK, S)
         dec.set_option(_lib.OPT_BLOCKS_PER_CU, blocks)
-        dec.set_option(_lib.OPT_REG_VARIANT, regs)
 
         def run():
             dec.decode_device(syn.data_ptr(), prior.data_ptr(), B, 50, 0, 1.0, 1.0, 20.0, flags,
@@ -61,7 +57,7 @@ def main():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); run(); b.record(); torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b))
-        r = dict(S=S, blocks_per_cu=blocks, regs=regs, threads=dec.info("threads"),
+        r = dict(S=S, blocks_per_cu=blocks, threads=dec.info("threads"),
                  grid=dec.info("grid"), lds=dec.info("lds_bytes"), ms=best, syn_per_s=B / best * 1e3)
         results.append(r)
         print(json.dumps(r), flush=True)
