@@ -79,3 +79,17 @@ def test_bp_osd_ler_matches_reference_curves():
                   f"{abs(ler - r) / sigma:.1f} sigma), OSD rate {row[6] / row[0]:.4f}")
             assert row[0] == T and row[10] == 0
             assert abs(ler - r) <= 4.0 * sigma
+
+
+def test_double_draw_noise_model_matches_reference_curve():
+    """data/3-BPOSD.npz: errors = XOR of two Bernoulli(p) draws (paperResults.py:61-63),
+    prior still from p, BP + OSD-0, 10 000 trials.  p = 0.01: [[72,12,6]] 0.0125, [[144,12,12]]
+    0.0009, [[288,12,18]] 0.0009.  500 000 device trials per point (draws = 2)."""
+    ref = {"[[72, 12, 6]]": 0.0125, "[[144, 12, 12]]": 0.0009, "[[288, 12, 18]]": 0.0009}
+    T = 500000
+    for name, r in ref.items():
+        row = mc.run_sweep(name, [0.01], T, draws=2, seed=4, osd=True)[0]
+        ler = row[1] / row[0]
+        sigma = np.hypot(np.sqrt(r * (1 - r) / 10000), np.sqrt(r * (1 - r) / T))
+        print(f"{name} double draw p=0.01: BP+OSD LER {ler:.5f} (reference {r}, {abs(ler - r) / sigma:.1f} sigma)")
+        assert abs(ler - r) <= 4.0 * sigma
