@@ -38,8 +38,11 @@ int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
-constexpr int DC_FUSED = 6;   // widest row / column the instantiated on-chip kernel handles
-constexpr int DV_FUSED = 3;
+// (row weight, column weight) shapes the on-chip kernel is instantiated for: every code of the
+// reference's codes/ is (6, 3); (8, 4) covers their space-time matrices (spaceTime.py: row weight
+// 6 + 2, column weight 3).  Anything wider, or with m > 1024, goes to the general-H kernel.
+constexpr int DC_SMALL = 6, DV_SMALL = 3;
+constexpr int DC_WIDE = 8, DV_WIDE = 4;
 
 template <typename T>
 struct DevBuf {
@@ -65,6 +68,7 @@ struct qbp_handle {
     int max_row_deg = 0, max_col_deg = 0;
     int num_cu = 0;
     bool fused_ok = false;
+    int dc = DC_SMALL, dv = DV_SMALL;   // instantiation used by this matrix
     bool padded = false;
     std::vector<int32_t> row_ptr, col_idx;
     // device tables for the fused kernel
@@ -110,13 +114,13 @@ namespace {
 using qbp::FusedParams;
 
 struct LaunchCfg {
-    int S, threads, lds_bytes, grid, slot_stride;
+    int S, threads, lds_bytes, grid, slot_stride, dc;
 };
 
-template <int VARIANT, bool MC, bool FORCE, int MAXT, int MINW>
+template <int DC, int DV, int VARIANT, bool MC, bool FORCE, int MAXT, int MINW>
 hipError_t launch_k(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
 {
-    auto kern = qbp::bp_fused_kernel<DC_FUSED, DV_FUSED, VARIANT, MC, FORCE, MAXT, MINW>;
+    auto kern = qbp::bp_fused_kernel<DC, DV, VARIANT, MC, FORCE, MAXT, MINW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
     if (e != hipSuccess) return e;
@@ -127,8 +131,12 @@ hipError_t launch_k(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stre
 template <int VARIANT, bool MC, int MAXT, int MINW = 1>
 hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
 {
-    return (P.flags & QBP_FLAG_FORCE_FULL) ? launch_k<VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
-                                           : launch_k<VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
+    const bool force = (P.flags & QBP_FLAG_FORCE_FULL) != 0;
+    if (cfg.dc == DC_SMALL)
+        return force ? launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
+                     : launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
+    return force ? launch_k<DC_WIDE, DV_WIDE, VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
+                 : launch_k<DC_WIDE, DV_WIDE, VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
 }
 
 template <bool MC>
@@ -158,9 +166,10 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     if ((long long)S > B) S = (int)std::max<long long>(B, 1);
     cfg->S = S;
     cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
-    cfg->slot_stride = DC_FUSED * m + 2;
-    size_t lds = ((size_t)S * cfg->slot_stride + (size_t)DC_FUSED * m + 2 * (size_t)S) * 8 +
-                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)DC_FUSED * m) * 4 +
+    cfg->dc = h->dc;
+    cfg->slot_stride = h->dc * m + 2;
+    size_t lds = ((size_t)S * cfg->slot_stride + (size_t)h->dc * m + 2 * (size_t)S) * 8 +
+                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)h->dc * m) * 4 +
                  (size_t)S * (((size_t)h->n + 3) / 4) * 4;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
@@ -191,7 +200,7 @@ int check_decode_args(qbp_handle* h, long long B, int max_iter, int variant, boo
         return fail(QBP_E_UNSUPPORTED,
                     "H (m=%d, max row degree %d, max column degree %d) does not fit the on-chip "
                     "kernel (m <= 1024, row degree <= %d, column degree <= %d)",
-                    h->m, h->max_row_deg, h->max_col_deg, DC_FUSED, DV_FUSED);
+                    h->m, h->max_row_deg, h->max_col_deg, DC_WIDE, DV_WIDE);
     return QBP_OK;
 }
 
@@ -255,8 +264,10 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QBP_E_HIP, "hipGetDeviceProperties failed"); }
     h->num_cu = prop.multiProcessorCount;
-    h->fused_ok = (m <= 1024) && max_row <= DC_FUSED && h->max_col_deg <= DV_FUSED &&
-                  ((size_t)(DC_FUSED * m + 2) * 8 + 64 <= 160 * 1024);
+    if (max_row <= DC_SMALL && h->max_col_deg <= DV_SMALL) { h->dc = DC_SMALL; h->dv = DV_SMALL; }
+    else { h->dc = DC_WIDE; h->dv = DV_WIDE; }
+    h->fused_ok = (m <= 1024) && max_row <= h->dc && h->max_col_deg <= h->dv &&
+                  ((size_t)(2 * h->dc * m + 2) * 8 + 4096 <= 160 * 1024);
 
     // ---- tables of the fused kernel -------------------------------------------------------
     // column lists in ascending check order: (check, position in that check's row)
@@ -275,7 +286,7 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
             e1 = hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice);
     };
     if (h->fused_ok) {
-        const int DC = DC_FUSED, DV = DV_FUSED;
+        const int DC = h->dc, DV = h->dv;
         const int zoff = DC * m;
         std::vector<int32_t> tab_var((size_t)DC * m, -1);
         std::vector<uint16_t> tab_nbr((size_t)DC * DV * m, (uint16_t)zoff);

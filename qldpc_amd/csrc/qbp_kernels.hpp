@@ -352,26 +352,35 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         double val[DC];
         if (active) {
             bool odd = sbit != 0;                                 // parity of the row vs syndrome
-            // issue all DC*DV LDS gathers before the first add (one lgkmcnt wait instead of DC*2)
-            double rr[DC][DV];
+            // Issue the LDS gathers of a group of edges before the first add (one lgkmcnt wait per
+            // group instead of two per edge); groups of at most 18 gathers keep the (8, 4) shape
+            // inside the register budget.
+            constexpr int JG = (DC * DV <= 18) ? DC : (DC + 1) / 2;
 #pragma unroll
-            for (int j = 0; j < DC; ++j)
+            for (int j0 = 0; j0 < DC; j0 += JG) {
+                double rr[JG][DV];
 #pragma unroll
-                for (int k = 0; k < DV; ++k) rr[j][k] = Rs[nbr[j][k]];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int jj = 0; jj < JG; ++jj)
 #pragma unroll
-            for (int j = 0; j < DC; ++j) {
-                double s = rr[j][0];
+                    for (int k = 0; k < DV; ++k)
+                        if (j0 + jj < DC) rr[jj][k] = Rs[nbr[j0 + jj][k]];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 1; k < DV; ++k) s = s + rr[j][k];   // ascending check order
-                val[j] = s + pri_lds[j * m + c];
-                odd ^= val[j] < 0.0;                              // hard decision: values < 0
-                const double qn = val[j] - R[j];
-                if constexpr (VARIANT == 0) {
-                    Q[j] = qn;
-                } else {
-                    const double q = P.damping * qn + one_minus_damping * Q[j];
-                    Q[j] = clipd_nan(q, -P.clip_llr, P.clip_llr);
+                for (int jj = 0; jj < JG; ++jj) {
+                    const int j = j0 + jj;
+                    if (j >= DC) break;
+                    double s = rr[jj][0];
+#pragma unroll
+                    for (int k = 1; k < DV; ++k) s = s + rr[jj][k];   // ascending check order
+                    val[j] = s + pri_lds[j * m + c];
+                    odd ^= val[j] < 0.0;                              // hard decision: values < 0
+                    const double qn = val[j] - R[j];
+                    if constexpr (VARIANT == 0) {
+                        Q[j] = qn;
+                    } else {
+                        const double q = P.damping * qn + one_minus_damping * Q[j];
+                        Q[j] = clipd_nan(q, -P.clip_llr, P.clip_llr);
+                    }
                 }
             }
             if (P.padded) {                                       // wave-uniform branch

@@ -15,8 +15,8 @@ def test_hip_matches_reference_goldens(tag):
     n_cases, worst = 0, (0.0, 0.0)
     for case in golden_util.load(tag):
         dec = bp.decoder_for(case["H"])
-        # 1 = fused on-chip kernel, 2 = general-H kernel (row weight > 6 or column weight > 3)
-        assert dec.info("kernel_kind") == (2 if tag in golden_util.IRREGULAR_TAGS else 1)
+        # 1 = fused on-chip kernel ((6,3) or (8,4) shape), 2 = general-H kernel (anything wider)
+        assert dec.info("kernel_kind") == (2 if tag == "rand" else 1)
         hard, conv, iters, llr = dec.decode(case["syndromes"], case["prior"], case["max_iter"],
                                             case["variant"], case["alpha"], case["damping"],
                                             case["clip_llr"])
@@ -171,7 +171,8 @@ def test_general_kernel_equals_fused_kernel_bitwise(name):
 
 def test_large_spacetime_matrix_vs_oracle():
     """[[144,12,12]] space-time matrix over 12 cycles (spaceTime.py:4-18): 864 x 2592, row weight
-    8 -- beyond the on-chip kernel's limits, decoded by the general-H kernel."""
+    8, column weight 3: the (8, 4) instantiation of the on-chip kernel; and the [[288,12,18]] one
+    over 4 cycles (m = 576)."""
     H = codes.load_code("[[144, 12, 12]]").Hx
     m, n = H.shape
     T = 12
@@ -184,8 +185,13 @@ def test_large_spacetime_matrix_vs_oracle():
     prior = np.full(Hst.shape[1], np.log(0.99 / 0.01))
     from scipy.sparse import csr_matrix
     dec = bp.decoder_for(csr_matrix(Hst))
-    assert dec.info("kernel_kind") == 2
+    assert dec.info("kernel_kind") == 1          # m = 864 <= 1024, row weight 8: the (8, 4) on-chip shape
     hard, conv, iters, llr = dec.decode(syn, prior, 50)
+    dec.set_option(_lib.OPT_FORCE_GENERIC, 1)    # and the general-H kernel gives the same bits
+    g = dec.decode(syn, prior, 50)
+    dec.set_option(_lib.OPT_FORCE_GENERIC, 0)
+    for x, y in zip((hard, conv, iters, llr), g):
+        assert np.array_equal(x, y)
     o = oracle.decode_batch(Hst, syn, prior, 50)
     assert np.array_equal(conv, o[1]) and np.array_equal(iters, o[2]) and np.array_equal(hard, o[0])
     fast = conv & (iters <= 20)

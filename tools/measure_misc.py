@@ -60,3 +60,21 @@ for pp, osd in ((0.01, False), (0.05, False), (0.05, True)):
     dt = time.perf_counter() - t0
     print(f"qbp_mc_run p={pp} osd={osd}: {T / dt:.3e} trials/s, LER {c[1] / c[0]:.5f}, "
           f"not converged {c[6] / c[0]:.4f}, mean iters {c[7] / c[0] + 1:.2f}")
+
+# space-time matrix of [[144,12,12]] over 12 cycles: (8, 4) on-chip shape vs general-H kernel
+from scipy.sparse import csr_matrix
+H = codes.load_code("[[144, 12, 12]]").Hx
+mm, T = H.shape[0], 12
+Hst = np.hstack([np.kron(np.eye(T, dtype=np.int64), H),
+                 (np.eye(mm * T, dtype=np.int64) + np.eye(mm * T, k=-mm, dtype=np.int64)) % 2])
+dst = bp.decoder_for(csr_matrix(Hst))
+err = (rng.random((4000, Hst.shape[1])) < 0.005).astype(np.int64)
+sst = (err @ Hst.T % 2).astype(np.uint8)
+pst = mc.prior_of(0.005, Hst.shape[1])
+for force in (0, 1):
+    dst.set_option(_lib.OPT_FORCE_GENERIC, force)
+    dst.decode(sst[:64], pst, 50, flags=_lib.FLAG_FORCE_FULL)
+    t0 = time.perf_counter()
+    dst.decode(sst, pst, 50, flags=_lib.FLAG_FORCE_FULL, want_llr=False)
+    dt = time.perf_counter() - t0
+    print(f"space-time 864x2592 {'general-H' if force else 'fused (8,4)'} kernel: {len(sst) / dt:.3e} syndromes/s forced 50")
