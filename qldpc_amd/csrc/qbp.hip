@@ -151,6 +151,16 @@ hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cf
     }
 }
 
+// Dynamic LDS of one workgroup of the fused kernel (the carve is documented in qbp_kernels.hpp)
+size_t fused_lds_bytes(int dc, int m, int n, int S)
+{
+    const size_t slot_stride = (size_t)dc * m + 2;
+    size_t lds = ((size_t)S * slot_stride + (size_t)dc * m + 2 * (size_t)S) * 8 +
+                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
+                 (size_t)S * (((size_t)n + 3) / 4) * 4;
+    return (lds + 15) & ~(size_t)15;
+}
+
 int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
 {
     const int m = h->m;
@@ -164,14 +174,12 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     }
     S = std::min(S, std::max(1, 1024 / std::max(m, 1)));
     if ((long long)S > B) S = (int)std::max<long long>(B, 1);
-    cfg->S = S;
-    cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
     cfg->dc = h->dc;
     cfg->slot_stride = h->dc * m + 2;
-    size_t lds = ((size_t)S * cfg->slot_stride + (size_t)h->dc * m + 2 * (size_t)S) * 8 +
-                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)h->dc * m) * 4 +
-                 (size_t)S * (((size_t)h->n + 3) / 4) * 4;
-    lds = (lds + 15) & ~(size_t)15;
+    while (S > 1 && fused_lds_bytes(h->dc, m, h->n, S) > 160 * 1024) --S;   // LDS-limited shapes
+    cfg->S = S;
+    cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
+    const size_t lds = fused_lds_bytes(h->dc, m, h->n, S);
     if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
     cfg->lds_bytes = (int)lds;
     int per_cu = h->opt_blocks_per_cu;
@@ -267,7 +275,7 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
     if (max_row <= DC_SMALL && h->max_col_deg <= DV_SMALL) { h->dc = DC_SMALL; h->dv = DV_SMALL; }
     else { h->dc = DC_WIDE; h->dv = DV_WIDE; }
     h->fused_ok = (m <= 1024) && max_row <= h->dc && h->max_col_deg <= h->dv &&
-                  ((size_t)(2 * h->dc * m + 2) * 8 + 4096 <= 160 * 1024);
+                  fused_lds_bytes(h->dc, m, n, 1) <= 160 * 1024;
 
     // ---- tables of the fused kernel -------------------------------------------------------
     // column lists in ascending check order: (check, position in that check's row)
