@@ -179,10 +179,13 @@ class Decoder:
         if pr.shape != (self.n,):
             raise ValueError(f"prior must have shape ({self.n},)")
         counters = np.zeros(NUM_COUNTERS, np.int64)
-        _check(load().qbp_mc_run(self._h, Lx.ctypes.data, Lx.shape[0], int(distance), float(p),
-                                 int(draws), int(seed), int(trial_begin), int(trial_end),
-                                 pr.ctypes.data, int(max_iter), int(variant), float(alpha),
-                                 float(damping), float(clip_llr), int(flags), counters.ctypes.data))
+        # with OSD a call keeps per-trial records on the device: split long ranges
+        step = MC_OSD_MAX_TRIALS if (int(flags) & FLAG_OSD0) else max(int(trial_end) - int(trial_begin), 1)
+        for a in range(int(trial_begin), int(trial_end), step):
+            _check(load().qbp_mc_run(self._h, Lx.ctypes.data, Lx.shape[0], int(distance), float(p),
+                                     int(draws), int(seed), a, min(a + step, int(trial_end)),
+                                     pr.ctypes.data, int(max_iter), int(variant), float(alpha),
+                                     float(damping), float(clip_llr), int(flags), counters.ctypes.data))
         return counters
 
     def mc_run_device(self, Lx, distance, p, d_prior, trial_begin, trial_end, d_counters, draws=1,
