@@ -102,7 +102,7 @@ struct qbp_handle {
     size_t pin_bytes = 0;
     // OSD-0
     bool osd_ok = false;
-    int osd_W = 0, osd_NP = 0, osd_lds = 0;
+    int osd_W = 0, osd_NP = 0, osd_lds = 0, osd_rank = 0;
     DevBuf<uint32_t> d_hbits;
     DevBuf<int32_t> d_row_ptr, d_col_idx;
     DevBuf<uint8_t> d_sol;
@@ -344,6 +344,23 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
                 for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e)
                     hbits[(size_t)c * W + (col_idx[e] >> 5)] |= 1u << (col_idx[e] & 31);
             up(h->d_hbits, hbits);
+            // rank of H over GF(2) (bit-packed Gaussian elimination on the host, once per code):
+            // the elimination loop of the kernel can stop as soon as that many pivots are found
+            std::vector<uint32_t> A = hbits;
+            int rank = 0;
+            for (int col = 0; col < n && rank < m; ++col) {
+                const int wi = col >> 5;
+                const uint32_t bit = 1u << (col & 31);
+                int piv = -1;
+                for (int r = rank; r < m; ++r) if (A[(size_t)r * W + wi] & bit) { piv = r; break; }
+                if (piv < 0) continue;
+                if (piv != rank) for (int w = 0; w < W; ++w) std::swap(A[(size_t)piv * W + w], A[(size_t)rank * W + w]);
+                for (int r = rank + 1; r < m; ++r)
+                    if (A[(size_t)r * W + wi] & bit)
+                        for (int w = 0; w < W; ++w) A[(size_t)r * W + w] ^= A[(size_t)rank * W + w];
+                ++rank;
+            }
+            h->osd_rank = rank;
         }
     }
     if (e1 == hipSuccess) e1 = h->d_work_counter.reserve(1);
@@ -570,7 +587,7 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
 {
     if (!h->osd_ok)
         return fail(QBP_E_UNSUPPORTED, "OSD-0 needs %d B of LDS for this H (limit 64 KiB)", h->osd_lds);
-    O.m = h->m; O.n = h->n; O.W = h->osd_W; O.NP = h->osd_NP;
+    O.m = h->m; O.n = h->n; O.W = h->osd_W; O.NP = h->osd_NP; O.rank = h->osd_rank;
     O.hbits = h->d_hbits.p; O.row_ptr = h->d_row_ptr.p; O.col_idx = h->d_col_idx.p;
     const long long grid = std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 32));
     hipLaunchKernelGGL(qbp::osd0_kernel, dim3((unsigned)grid), dim3(64), h->osd_lds, s, O);

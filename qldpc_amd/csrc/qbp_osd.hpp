@@ -20,6 +20,7 @@ struct OsdParams {
     // code
     int m, n, W;                    // W = 32-bit words per row of H ((n + 31) / 32)
     int NP;                         // power of two >= n (sort width)
+    int rank;                       // rank of H over GF(2): no pivot exists beyond it
     const uint32_t* hbits;          // [m][W] bit-packed rows of H
     const int32_t* row_ptr;         // CSR of H
     const int32_t* col_idx;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
         __syncthreads();
         // ---- 3. Gauss-Jordan over the columns in reliability order            OSD.py:31-72
         int rank = 0;
-        for (int k = 0; k < n && rank < m; ++k) {
+        for (int k = 0; k < n && rank < P.rank; ++k) {   // :42-43 stops at m rows; rank(H) <= m
             const int c = idx[k];
             const int wi = c >> 5;
             const uint32_t bit = 1u << (c & 31);
