@@ -11,11 +11,14 @@ from qldpc_amd import codes
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide.npz")
 CASES = [(t, p) for t in ("72", "144", "288") for p in (0.03, 0.06, 0.09)]
+# [[144,12,12]] with the other update rules: (key prefix, variant, kwargs)
+VARIANT_CASES = [("144minsum", 2, dict(alpha=0.8, damping=0.7, clip_llr=25.0), p) for p in (0.04, 0.08)] + \
+                [("144sym", 1, dict(alpha=1.0, damping=0.8, clip_llr=20.0), p) for p in (0.04, 0.08)]
 
 
 def load(tag, p):
     d = np.load(GOLD)
-    code = codes.load_code(tag)
+    code = codes.load_code("144" if tag.startswith("144") else tag)
     m, n = code.Hx.shape
     k = f"{tag}/p{p}"
     syn = np.unpackbits(d[f"{k}/syndromes"], axis=1)[:, :m]
@@ -54,3 +57,30 @@ def test_oracle_wide(tag, p):
 def test_device_wide(tag, p):
     from qldpc_amd import bp
     check(tag, p, lambda H, s, pr: bp.decoder_for(H).decode(s.astype(np.uint8), pr, 50), "device")
+
+
+def check_variant(prefix, variant, kw, p, decode, who):
+    code, syn, hard, conv, iters, llr_sum = load(prefix, p)
+    prior = np.full(code.n, np.log((1 - p) / p))
+    h, c, it, llr = decode(code.Hx, syn, prior, variant, kw)
+    fast = conv & (iters <= 20)
+    rel = np.abs(llr.sum(1) - llr_sum) / np.maximum(np.abs(llr_sum), 1e-300)
+    bad = int((c != conv).sum()) + int((it != iters).sum()) + int((h != hard).any(1).sum())
+    print(f"{who} {prefix} p={p}: 1000 syndromes, {int(conv.sum())} converged, {bad} mismatches vs the "
+          f"reference, LLR-sum rel err {rel[fast].max():.1e}")
+    assert np.array_equal(c, conv) and np.array_equal(it, iters) and np.array_equal(h, hard)
+    assert rel[fast].max() <= (1e-12 if variant == 2 else 1e-5)     # min-sum has no transcendental
+
+
+@pytest.mark.parametrize("prefix,variant,kw,p", VARIANT_CASES)
+def test_oracle_wide_variants(prefix, variant, kw, p):
+    check_variant(prefix, variant, kw, p,
+                  lambda H, s, pr, v, k: oracle.decode_batch(H, s, pr, 50, v, **k), "oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prefix,variant,kw,p", VARIANT_CASES)
+def test_device_wide_variants(prefix, variant, kw, p):
+    from qldpc_amd import bp
+    check_variant(prefix, variant, kw, p,
+                  lambda H, s, pr, v, k: bp.decoder_for(H).decode(s.astype(np.uint8), pr, 50, v, **k), "device")
