@@ -270,3 +270,36 @@ def test_c_example_runs_on_gpu(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "converged 1 at iteration 0: 0010000" in r.stdout
     assert "1.06635143 1.06635143 -0.06452172 3.32809773 2.19722458 2.19722458 1.06635143" in r.stdout
+
+
+def test_handle_lifecycle_and_input_types():
+    """Many handles created / destroyed, two codes interleaved, and the input spellings the
+    reference's callers use: int64 syndromes from (e @ H.T) % 2, bool detection
+    events (studyComplete.py:94-97), int8, Python lists; prior as a list of np.float64 (main.py:18)."""
+    c72, c144 = codes.load_code("[[72, 12, 6]]"), codes.load_code("[[144, 12, 12]]")
+    rng = np.random.default_rng(31)
+    e72 = (rng.random((50, 72)) < 0.04).astype(np.int64)
+    s72 = (e72 @ c72.Hx.T) % 2
+    prior72 = [np.log((1 - 0.04) / 0.04)] * 72
+    ref = oracle.decode_batch(c72.Hx, s72, prior72, 50)
+    for i in range(40):                         # fresh handle every time (cache bypassed)
+        d = _lib.Decoder(*bp.csr_from_H(c72.Hx if i % 2 == 0 else c144.Hx))
+        if i % 2 == 0:
+            out = d.decode(s72.astype(np.uint8), np.asarray(prior72), 50)
+            assert np.array_equal(out[0], ref[0]) and np.array_equal(out[2], ref[2])
+        d.close()
+        d.close()                               # idempotent
+    for k, s in enumerate(s72[:6]):
+        want = (ref[0][k].astype(np.int8), bool(ref[1][k]))
+        for spelled in (s, s.astype(bool), s.astype(np.int8), s.tolist(), s.astype(np.float64)):
+            det, ok, llr = bp.performBeliefPropagationFast(c72.Hx, spelled, prior72, verbose=False)
+            assert np.array_equal(det, want[0]) and ok == want[1]
+        det, ok, llr, it = __import__("qldpc_amd.rework", fromlist=["x"]).performBeliefPropagationFast(
+            c72.Hx.astype(np.float64), s, np.asarray(prior72))
+        assert it == ref[2][k] and np.array_equal(det, want[0])
+    with pytest.raises(ValueError):
+        bp.performBeliefPropagationFast(c72.Hx, s72[0][:10], prior72, verbose=False)
+    with pytest.raises(ValueError):
+        bp.performBeliefPropagationFast(c72.Hx, s72[0], prior72[:5], verbose=False)
+    with pytest.raises(ValueError):
+        bp.performBeliefPropagationFast(c72.Hx, s72[0] * 2, prior72, verbose=False)
