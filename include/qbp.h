@@ -66,6 +66,18 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
 void qbp_destroy(qbp_handle* h);
 
 /*
+ * Host-only: what qbp_create would derive from the same CSR arrays, without touching a device
+ * (used by the CPU test-suite).  info[8] = {kernel kind (1 on-chip, 2 general-H), DC, DV, max row
+ * weight, max column weight, isolated variables, padded (0/1), LDS bytes of one slot}.  When the
+ * on-chip kernel applies, the optional outputs receive its tables: tab_var [DC][m] (variable of
+ * edge j of check c, -1 = padding), tab_nbr [DC][DV][m] (LDS word offsets j'*m + c' of the column
+ * of that variable in ascending check order, DC*m = the zero word), tab_writer [m] (bit j: edge
+ * (c, j) is the first of its column).
+ */
+int qbp_plan(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n, int32_t info[8],
+             int32_t* tab_var, uint16_t* tab_nbr, uint32_t* tab_writer);
+
+/*
  * Decode B syndromes (host buffers).
  *   syndromes [B][m] 0/1 bytes, prior [n] LLRs (initialBelief), max_iter >= 1,
  *   variant QBP_*, alpha / damping / clip_llr as in rework/decoding.py (ignored by

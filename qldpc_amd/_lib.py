@@ -32,6 +32,7 @@ _VP = C.c_void_p
 SIGNATURES = {
     "qbp_create": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "qbp_destroy": (None, [_VP]),
+    "qbp_plan": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),
     "qbp_decode_batch": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_double,
                                    C.c_double, C.c_double, C.c_uint32, _VP, _VP, _VP, _VP]),
     "qbp_decode_batch_device": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32,

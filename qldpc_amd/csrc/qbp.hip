@@ -165,6 +165,73 @@ size_t fused_lds_bytes(int dc, int m, int n, int S)
     return (lds + 15) & ~(size_t)15;
 }
 
+// Everything qbp_create derives from the CSR arrays on the host (no device involved; qbp_plan
+// exposes it so that the CPU test-suite can check the tables).
+struct HostTables {
+    int max_row = 0, max_col = 0, dc = DC_SMALL, dv = DV_SMALL;
+    bool fused_ok = false, padded = false;
+    std::vector<int32_t> tab_var;      // [dc][m]
+    std::vector<uint16_t> tab_nbr;     // [dc][dv][m]
+    std::vector<uint32_t> tab_writer;  // [m]
+    std::vector<int32_t> iso, col_ptr, col_edge;
+};
+
+int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, HostTables& T)
+{
+    if (!row_ptr || m < 0 || n < 0) return fail(QBP_E_INVALID, "bad matrix arguments");
+    if (m == 0 || n == 0) return fail(QBP_E_INVALID, "empty matrix (%d x %d)", m, n);
+    if (row_ptr[0] != 0) return fail(QBP_E_INVALID, "row_ptr[0] must be 0");
+    const int E = row_ptr[m];
+    if (E < 0 || (E > 0 && !col_idx)) return fail(QBP_E_INVALID, "bad CSR arrays");
+    // column lists in ascending check order: (check, position in that check's row)
+    std::vector<std::vector<std::pair<int, int>>> cols(n);
+    for (int c = 0; c < m; ++c) {
+        if (row_ptr[c + 1] < row_ptr[c]) return fail(QBP_E_INVALID, "row_ptr not monotone at %d", c);
+        T.max_row = std::max(T.max_row, row_ptr[c + 1] - row_ptr[c]);
+        for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e) {
+            if (col_idx[e] < 0 || col_idx[e] >= n)
+                return fail(QBP_E_INVALID, "column index %d out of range in row %d", col_idx[e], c);
+            if (e > row_ptr[c] && col_idx[e] <= col_idx[e - 1])
+                return fail(QBP_E_INVALID, "columns of row %d not strictly ascending", c);
+            cols[col_idx[e]].push_back({c, e - row_ptr[c]});
+        }
+    }
+    for (int v = 0; v < n; ++v) {
+        T.max_col = std::max(T.max_col, (int)cols[v].size());
+        if (cols[v].empty()) T.iso.push_back(v);
+    }
+    if (T.max_row <= DC_SMALL && T.max_col <= DV_SMALL) { T.dc = DC_SMALL; T.dv = DV_SMALL; }
+    else { T.dc = DC_WIDE; T.dv = DV_WIDE; }
+    T.fused_ok = (m <= 1024) && T.max_row <= T.dc && T.max_col <= T.dv &&
+                 fused_lds_bytes(T.dc, m, n, 1) <= 160 * 1024;
+    if (T.fused_ok) {
+        const int DC = T.dc, DV = T.dv, zoff = DC * m;
+        T.tab_var.assign((size_t)DC * m, -1);
+        T.tab_nbr.assign((size_t)DC * DV * m, (uint16_t)zoff);
+        T.tab_writer.assign(m, 0u);
+        for (int c = 0; c < m; ++c) {
+            const int deg = row_ptr[c + 1] - row_ptr[c];
+            if (deg < DC) T.padded = true;
+            for (int j = 0; j < deg; ++j) {
+                const int v = col_idx[row_ptr[c] + j];
+                T.tab_var[(size_t)j * m + c] = v;
+                const auto& col = cols[v];
+                for (size_t k = 0; k < col.size(); ++k)
+                    T.tab_nbr[((size_t)j * DV + k) * m + c] = (uint16_t)(col[k].second * m + col[k].first);
+                if (col[0].first == c) T.tab_writer[c] |= 1u << j;
+            }
+        }
+    }
+    // CSC (edge ids per column, ascending check) for the general-H kernel
+    T.col_ptr.assign((size_t)n + 1, 0);
+    T.col_edge.assign((size_t)std::max(E, 1), 0);
+    for (int v = 0; v < n; ++v) T.col_ptr[v + 1] = T.col_ptr[v] + (int)cols[v].size();
+    for (int v = 0; v < n; ++v)
+        for (size_t k = 0; k < cols[v].size(); ++k)
+            T.col_edge[T.col_ptr[v] + k] = row_ptr[cols[v][k].first] + cols[v][k].second;
+    return QBP_OK;
+}
+
 int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
 {
     const int m = h->m;
@@ -241,24 +308,10 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
 {
     if (!out) return fail(QBP_E_INVALID, "out is null");
     *out = nullptr;
-    if (!row_ptr || m < 0 || n < 0) return fail(QBP_E_INVALID, "bad matrix arguments");
-    if (m == 0 || n == 0) return fail(QBP_E_INVALID, "empty matrix (%d x %d)", m, n);
-    if (row_ptr[0] != 0) return fail(QBP_E_INVALID, "row_ptr[0] must be 0");
+    HostTables T;
+    int rc0 = build_tables(row_ptr, col_idx, m, n, T);
+    if (rc0) return rc0;
     const int E = row_ptr[m];
-    if (E < 0 || (E > 0 && !col_idx)) return fail(QBP_E_INVALID, "bad CSR arrays");
-    std::vector<int> col_deg(n, 0);
-    int max_row = 0;
-    for (int c = 0; c < m; ++c) {
-        if (row_ptr[c + 1] < row_ptr[c]) return fail(QBP_E_INVALID, "row_ptr not monotone at %d", c);
-        max_row = std::max(max_row, row_ptr[c + 1] - row_ptr[c]);
-        for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e) {
-            if (col_idx[e] < 0 || col_idx[e] >= n)
-                return fail(QBP_E_INVALID, "column index %d out of range in row %d", col_idx[e], c);
-            if (e > row_ptr[c] && col_idx[e] <= col_idx[e - 1])
-                return fail(QBP_E_INVALID, "columns of row %d not strictly ascending", c);
-            col_deg[col_idx[e]]++;
-        }
-    }
     int ndev = 0;
     hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev <= 0)
@@ -273,25 +326,14 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
     h->device = device; h->m = m; h->n = n; h->E = E;
     h->row_ptr.assign(row_ptr, row_ptr + m + 1);
     h->col_idx.assign(col_idx, col_idx + E);
-    h->max_row_deg = max_row;
-    h->max_col_deg = *std::max_element(col_deg.begin(), col_deg.end());
+    h->max_row_deg = T.max_row;
+    h->max_col_deg = T.max_col;
+    h->dc = T.dc; h->dv = T.dv; h->fused_ok = T.fused_ok; h->padded = T.padded;
+    h->n_iso = (int)T.iso.size();
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QBP_E_HIP, "hipGetDeviceProperties failed"); }
     h->num_cu = prop.multiProcessorCount;
-    if (max_row <= DC_SMALL && h->max_col_deg <= DV_SMALL) { h->dc = DC_SMALL; h->dv = DV_SMALL; }
-    else { h->dc = DC_WIDE; h->dv = DV_WIDE; }
-    h->fused_ok = (m <= 1024) && max_row <= h->dc && h->max_col_deg <= h->dv &&
-                  fused_lds_bytes(h->dc, m, n, 1) <= 160 * 1024;
 
-    // ---- tables of the fused kernel -------------------------------------------------------
-    // column lists in ascending check order: (check, position in that check's row)
-    std::vector<std::vector<std::pair<int, int>>> cols(n);
-    for (int c = 0; c < m; ++c)
-        for (int e = row_ptr[c]; e < row_ptr[c + 1]; ++e)
-            cols[col_idx[e]].push_back({c, e - row_ptr[c]});
-    std::vector<int32_t> iso;
-    for (int v = 0; v < n; ++v) if (cols[v].empty()) iso.push_back(v);
-    h->n_iso = (int)iso.size();
     hipError_t e1 = hipSuccess;
     auto up = [&](auto& buf, const auto& vec) {
         if (e1 != hipSuccess) return;
@@ -299,40 +341,16 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
         if (e1 == hipSuccess && !vec.empty())
             e1 = hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice);
     };
-    if (h->fused_ok) {
-        const int DC = h->dc, DV = h->dv;
-        const int zoff = DC * m;
-        std::vector<int32_t> tab_var((size_t)DC * m, -1);
-        std::vector<uint16_t> tab_nbr((size_t)DC * DV * m, (uint16_t)zoff);
-        std::vector<uint32_t> tab_writer(m, 0u);
-        for (int c = 0; c < m; ++c) {
-            const int deg = row_ptr[c + 1] - row_ptr[c];
-            if (deg < DC) h->padded = true;
-            for (int j = 0; j < deg; ++j) {
-                const int v = col_idx[row_ptr[c] + j];
-                tab_var[(size_t)j * m + c] = v;
-                const auto& col = cols[v];
-                for (size_t k = 0; k < col.size(); ++k)
-                    tab_nbr[((size_t)j * DV + k) * m + c] = (uint16_t)(col[k].second * m + col[k].first);
-                if (col[0].first == c) tab_writer[c] |= 1u << j;
-            }
-        }
-        up(h->d_tab_var, tab_var);
-        up(h->d_tab_nbr, tab_nbr);
-        up(h->d_tab_writer, tab_writer);
+    if (T.fused_ok) {
+        up(h->d_tab_var, T.tab_var);
+        up(h->d_tab_nbr, T.tab_nbr);
+        up(h->d_tab_writer, T.tab_writer);
     }
-    up(h->d_iso, iso);
-    {   // CSR + CSC (edge ids per column, ascending check) for the general-H kernel
-        std::vector<int32_t> col_ptr(n + 1, 0), col_edge((size_t)std::max(E, 1));
-        for (int v = 0; v < n; ++v) col_ptr[v + 1] = col_ptr[v] + (int)cols[v].size();
-        for (int v = 0; v < n; ++v)
-            for (size_t k = 0; k < cols[v].size(); ++k)
-                col_edge[col_ptr[v] + k] = row_ptr[cols[v][k].first] + cols[v][k].second;
-        up(h->d_col_ptr, col_ptr);
-        up(h->d_col_edge, col_edge);
-        up(h->d_row_ptr, h->row_ptr);
-        up(h->d_col_idx, h->col_idx);
-    }
+    up(h->d_iso, T.iso);
+    up(h->d_col_ptr, T.col_ptr);
+    up(h->d_col_edge, T.col_edge);
+    up(h->d_row_ptr, h->row_ptr);
+    up(h->d_col_idx, h->col_idx);
     {   // OSD-0: bit-packed rows of H and its CSR
         const int W = (n + 31) / 32;
         int NP = 1;
@@ -374,6 +392,25 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
         return rc;
     }
     *out = h;
+    return QBP_OK;
+}
+
+int qbp_plan(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n, int32_t info[8],
+             int32_t* tab_var, uint16_t* tab_nbr, uint32_t* tab_writer)
+{
+    HostTables T;
+    int rc = build_tables(row_ptr, col_idx, m, n, T);
+    if (rc) return rc;
+    if (info) {
+        info[0] = T.fused_ok ? 1 : 2; info[1] = T.dc; info[2] = T.dv; info[3] = T.max_row;
+        info[4] = T.max_col; info[5] = (int32_t)T.iso.size(); info[6] = T.padded ? 1 : 0;
+        info[7] = T.fused_ok ? (int32_t)fused_lds_bytes(T.dc, m, n, 1) : 0;
+    }
+    if (T.fused_ok) {
+        if (tab_var) std::memcpy(tab_var, T.tab_var.data(), T.tab_var.size() * sizeof(int32_t));
+        if (tab_nbr) std::memcpy(tab_nbr, T.tab_nbr.data(), T.tab_nbr.size() * sizeof(uint16_t));
+        if (tab_writer) std::memcpy(tab_writer, T.tab_writer.data(), T.tab_writer.size() * sizeof(uint32_t));
+    }
     return QBP_OK;
 }
 

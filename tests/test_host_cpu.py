@@ -137,3 +137,65 @@ def test_header_is_plain_c_and_library_links_from_c(lib, tmp_path):
         assert r.returncode == 0 and "converged 1 at iteration 0: 0010000" in r.stdout
     else:
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+def _plan(lib, H):
+    rp, ci, m, n = bp.csr_from_H(H)
+    info = np.zeros(8, np.int32)
+    assert lib.qbp_plan(rp.ctypes.data, ci.ctypes.data, m, n, info.ctypes.data, None, None, None) == 0
+    kind, dc, dv = int(info[0]), int(info[1]), int(info[2])
+    tabs = None
+    if kind == 1:
+        tv = np.zeros((dc, m), np.int32)
+        tn = np.zeros((dc, dv, m), np.uint16)
+        tw = np.zeros(m, np.uint32)
+        assert lib.qbp_plan(rp.ctypes.data, ci.ctypes.data, m, n, info.ctypes.data, tv.ctypes.data,
+                            tn.ctypes.data, tw.ctypes.data) == 0
+        tabs = (tv, tn, tw)
+    return info, tabs, (rp, ci, m, n)
+
+
+def test_host_tables_of_the_on_chip_kernel(lib):
+    """qbp_plan (host only): the gather tables the fused kernel runs on.  For every edge (c, j) of
+    variable v the DV offsets must list v's column in ascending check order, padded with the zero
+    word; exactly one edge per variable is its writer; padding edges have no variable."""
+    from scipy.sparse import csr_matrix
+    c144 = codes.load_code("[[144, 12, 12]]").Hx
+    st = np.hstack([np.kron(np.eye(3, dtype=np.int64), c144),
+                    (np.eye(216, dtype=np.int64) + np.eye(216, k=-72, dtype=np.int64)) % 2])
+    for H, want in ((codes.load_code("steane").Hx, (1, 6, 3)), (codes.load_code("[[288, 12, 18]]").Hx, (1, 6, 3)),
+                    (st, (1, 8, 4))):
+        info, tabs, (rp, ci, m, n) = _plan(lib, H)
+        assert tuple(info[:3]) == want
+        tv, tn, tw = tabs
+        dc, dv = want[1], want[2]
+        S = csr_matrix(H)
+        Hc = S.tocsc()
+        Hc.sort_indices()
+        writers = np.zeros(n, int)
+        for c in range(m):
+            row = ci[rp[c]:rp[c + 1]]
+            assert np.array_equal(tv[:len(row), c], row) and (tv[len(row):, c] == -1).all()
+            for j, v in enumerate(row):
+                col_checks = Hc.indices[Hc.indptr[v]:Hc.indptr[v + 1]]          # ascending checks
+                for k in range(dv):
+                    off = int(tn[j, k, c])
+                    if k < len(col_checks):
+                        cc = int(col_checks[k])
+                        jj = int(np.searchsorted(ci[rp[cc]:rp[cc + 1]], v))
+                        assert off == jj * m + cc
+                    else:
+                        assert off == dc * m                                        # the zero word
+                writers[v] += (int(tw[c]) >> j) & 1
+                assert ((int(tw[c]) >> j) & 1) == int(col_checks[0] == c)
+            assert (tn[len(row):, :, c] == dc * m).all()
+        assert np.array_equal(writers, (np.asarray(H) != 0).any(0).astype(int))
+        assert info[6] == int((np.asarray(H) != 0).sum(1).min() < dc)
+    # shapes that do not fit: wide rows -> general-H kernel; m > 1024 -> general-H kernel
+    rng = np.random.default_rng(0)
+    wide = (rng.random((20, 60)) < 0.4).astype(np.int64)
+    assert _plan(lib, wide)[0][0] == 2
+    big = np.kron(np.eye(8, dtype=np.int64), c144)                                   # m = 576 fits
+    assert _plan(lib, big)[0][0] == 1
+    big = np.kron(np.eye(16, dtype=np.int64), c144)                                  # m = 1152
+    assert _plan(lib, csr_matrix(big))[0][0] == 2
