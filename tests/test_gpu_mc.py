@@ -73,3 +73,22 @@ def test_non_convergence_rate_matches_reference_data():
             print(f"{name} p={p}: not converged {rate:.4f} (reference {r}, {abs(rate - r) / sigma:.1f} sigma), "
                   f"LER {c[1] / c[0]:.4f}")
             assert abs(rate - r) <= 4.0 * sigma
+
+
+def test_paper_results_driver_end_to_end(tmp_path, capsys):
+    """The paperResults_GPU.py replacement: runs a small sweep on the device and writes the
+    reference's result schema (results[code][key] = list over the error rates)."""
+    from qldpc_amd import paper_results
+    out = str(tmp_path / "BPOSD_MI355X")
+    paper_results.main(["--codes", "72", "144", "--p", "0.05", "0.02", "--trials", "20000",
+                        "--max-iter", "50", "--out", out])
+    printed = capsys.readouterr().out
+    assert "Processing code: [[72, 12, 6]]" in printed and "LER=" in printed
+    res = np.load(out + ".npz", allow_pickle=True)["results"].item()
+    assert list(res) == ["[[72, 12, 6]]", "[[144, 12, 12]]"]
+    for name in res:
+        assert set(res[name]) == set(paper_results.KEYS)
+        assert len(res[name]["ler"]) == 2 and res[name]["ler"][0] > res[name]["ler"][1] > 0
+        assert res[name]["BPs_fault"] == [0, 0]
+    # double draw at p = 0.05 on [[72,12,6]] with OSD-0: LER around 0.6 (effective p = 0.095)
+    assert 0.45 < res["[[72, 12, 6]]"]["ler"][0] < 0.75
