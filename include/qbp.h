@@ -164,6 +164,8 @@ enum {
     QBP_OPT_SLOTS_PER_BLOCK = 1, /* syndromes decoded concurrently by one workgroup (0 = auto) */
     QBP_OPT_BLOCKS_PER_CU = 2,   /* persistent workgroups per CU (0 = auto)                    */
     QBP_OPT_FORCE_GENERIC = 4,   /* 1 = use the general-H kernel even where the on-chip one fits */
+    QBP_OPT_KERNEL = 5,          /* 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome),
+                                    3 streaming (lane per syndrome, messages in HBM)          */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
     QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 fused on-chip, 2 generic */
     QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109

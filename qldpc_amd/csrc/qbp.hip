@@ -14,6 +14,7 @@
 #include "qbp_kernels.hpp"
 #include "qbp_osd.hpp"
 #include "qbp_generic.hpp"
+#include "qbp_stream.hpp"
 
 static_assert(QBP_NUM_COUNTERS == qbp::NUM_COUNTERS, "counter layout");
 
@@ -96,6 +97,8 @@ struct qbp_handle {
     DevBuf<double> d_wsQ, d_wsR, d_wsV;
     DevBuf<uint8_t> d_wsC;
     int opt_force_generic = 0;
+    int opt_kernel = 0;             // 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome), 3 streaming
+    DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes
     // pinned, device-mapped staging for small host-pointer calls (zero-copy: no hipMemcpy at all)
     void* pin_host = nullptr;
     void* pin_dev = nullptr;
@@ -425,7 +428,7 @@ void qbp_destroy(qbp_handle* h)
     h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
     if (h->pin_host) (void)hipHostFree(h->pin_host);
     h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
-    h->d_wsV.release(); h->d_wsC.release();
+    h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
@@ -463,6 +466,45 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     return QBP_OK;
 }
 
+static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior, int64_t B,
+                         int max_iter, int variant, double alpha, double damping, double clip_llr,
+                         unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
+                         double* d_llr, hipStream_t s)
+{
+    // streaming kernel: one lane per syndrome, messages [edge][syndrome] in a global workspace;
+    // long batches go through in chunks that keep the workspace under 16 GiB
+    const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n, m = (size_t)h->m;
+    const size_t per_lane = 2 * E * sizeof(double) + n + m;
+    long long Bc = (long long)std::min<unsigned long long>(((unsigned long long)16 << 30) / per_lane,
+                                                          (unsigned long long)B);
+    Bc = std::max<long long>(256, (Bc + 255) / 256 * 256);
+    HIP_TRY(h->d_wsQ.reserve((size_t)Bc * E));
+    HIP_TRY(h->d_wsR.reserve((size_t)Bc * E));
+    HIP_TRY(h->d_wsC.reserve((size_t)Bc * n));
+    HIP_TRY(h->d_wsS.reserve((size_t)Bc * m));
+    qbp::StreamParams P{};
+    P.m = h->m; P.n = h->n; P.E = h->E;
+    P.row_ptr = h->d_row_ptr.p; P.col_idx = h->d_col_idx.p;
+    P.col_ptr = h->d_col_ptr.p; P.col_edge = h->d_col_edge.p;
+    P.syndromes = d_syndromes; P.prior = d_prior; P.B = B; P.Bc = Bc;
+    P.max_iter = max_iter; P.flags = flags; P.alpha = alpha; P.damping = damping; P.clip_llr = clip_llr;
+    P.hard = d_hard; P.converged = d_converged; P.iters = d_iters; P.llr = d_llr;
+    P.Q = h->d_wsQ.p; P.R = h->d_wsR.p; P.cand = h->d_wsC.p; P.synT = h->d_wsS.p;
+    for (long long b0 = 0; b0 < B; b0 += Bc) {
+        P.b0 = b0;
+        const long long lanes = std::min<long long>(Bc, B - b0);
+        const unsigned grid = (unsigned)((lanes + 255) / 256);
+        h->last_threads = 256; h->last_lds = 0; h->last_grid = (int)grid;
+        switch (variant) {
+            case QBP_SUM_PRODUCT: hipLaunchKernelGGL((qbp::bp_stream_kernel<0, 8>), dim3(grid), dim3(256), 0, s, P, P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior); break;
+            case QBP_DAMPED_SP:   hipLaunchKernelGGL((qbp::bp_stream_kernel<1, 8>), dim3(grid), dim3(256), 0, s, P, P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior); break;
+            default:              hipLaunchKernelGGL((qbp::bp_stream_kernel<2, 8>), dim3(grid), dim3(256), 0, s, P, P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return QBP_OK;
+}
+
 int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior,
                             int64_t B, int32_t max_iter, int32_t variant, double alpha,
                             double damping, double clip_llr, uint32_t flags, uint8_t* d_hard,
@@ -475,7 +517,16 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     if (B > (int64_t)1 << 40) return fail(QBP_E_INVALID, "B too large");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!h->fused_ok || h->opt_force_generic)
+    // kernel choice: the on-chip kernel when the matrix fits; otherwise one lane per syndrome
+    // (streaming) for batches large enough to fill the chip, one workgroup per syndrome below that
+    int kernel = h->opt_kernel;
+    if (h->opt_force_generic) kernel = 2;
+    if (kernel == 1 && !h->fused_ok) return fail(QBP_E_UNSUPPORTED, "H does not fit the on-chip kernel");
+    if (kernel == 0) kernel = h->fused_ok ? 1 : (B >= 16384 ? 3 : 2);
+    if (kernel == 3)
+        return stream_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr, flags,
+                             d_hard, d_converged, d_iters, d_llr, s);
+    if (kernel == 2)
         return generic_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr,
                               flags, d_hard, d_converged, d_iters, d_llr, nullptr, 0, 1.0, s);
     LaunchCfg cfg;
@@ -805,6 +856,9 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
             h->opt_blocks_per_cu = (int)value; return QBP_OK;
         case QBP_OPT_FORCE_GENERIC:
             h->opt_force_generic = value != 0; return QBP_OK;
+        case QBP_OPT_KERNEL:
+            if (value < 0 || value > 3) return fail(QBP_E_INVALID, "kernel selector out of range");
+            h->opt_kernel = (int)value; return QBP_OK;
         default: return fail(QBP_E_INVALID, "unknown option %d", option);
     }
 }
@@ -818,7 +872,10 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
         case QBP_INFO_EDGES: return h->E;
         case QBP_INFO_MAX_ROW_DEG: return h->max_row_deg;
         case QBP_INFO_MAX_COL_DEG: return h->max_col_deg;
-        case QBP_INFO_KERNEL_KIND: return (h->fused_ok && !h->opt_force_generic) ? 1 : 2;
+        case QBP_INFO_KERNEL_KIND:
+            if (h->opt_force_generic) return 2;
+            if (h->opt_kernel) return h->opt_kernel;
+            return h->fused_ok ? 1 : 2;   // (auto picks 3 for batches >= 16384 when not on-chip)
         case QBP_INFO_THREADS: return h->last_threads;
         case QBP_INFO_LDS_BYTES: return h->last_lds;
         case QBP_INFO_GRID: return h->last_grid;

@@ -1,0 +1,307 @@
+// Streaming belief propagation: one LANE per syndrome, messages in HBM.
+//
+// The on-chip kernel (qbp_kernels.hpp) keeps a syndrome's messages in registers/LDS and is bounded
+// by the FP64 vector ALU; it needs m <= 1024 and narrow rows/columns.  This kernel is the other
+// design point: for matrices of any size the messages live in
+// global memory as structure-of-arrays [edge][syndrome], every lane of a wavefront decodes its own
+// syndrome, and all indices of H are wave-uniform (scalar loads) -- so every message access is a
+// fully coalesced 512-byte wave transaction and there are no barriers, no LDS, no atomics.  Per
+// iteration and syndrome it moves exactly the algorithmic bytes of SURVEY 8(d): read Q, write R
+// (check step), read R, write Q (variable step) = 4 * E * 8 bytes (5 * E * 8 for the damped
+// variants, which also read the old Q) plus n + E bytes of hard-decision traffic: its HBM traffic
+// measured by the PMC counters IS the roofline figure, not an effective bandwidth.
+//
+// Arithmetic and order are those of the other kernels (ascending column within a row, ascending
+// check within a column), so outputs are bit-identical to theirs (tested).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qbp_math.hpp"
+
+namespace qbp {
+
+struct StreamParams {
+    int m, n, E;
+    const int32_t* row_ptr;     // CSR
+    const int32_t* col_idx;
+    const int32_t* col_ptr;     // CSC: edge ids of each column, ascending check
+    const int32_t* col_edge;
+    const uint8_t* syndromes;   // [B][m]
+    const double* prior;        // [n]
+    long long B;                // syndromes in the whole call
+    long long b0;               // first syndrome of this launch (chunk)
+    long long Bc;               // lanes of this launch = row stride of the workspace arrays
+    int max_iter;
+    unsigned flags;
+    double alpha, damping, clip_llr;
+    uint8_t* hard;              // [B][n]
+    uint8_t* converged;
+    int32_t* iters;
+    double* llr;                // [B][n]
+    double* Q;                  // [E][Bc]
+    double* R;                  // [E][Bc]
+    uint8_t* cand;              // [n][Bc] candidate error of the current iteration
+    uint8_t* synT;              // [m][Bc] syndromes, transposed once at the start
+};
+
+// DMAX: rows / columns of at most DMAX entries keep their working values in registers; longer ones
+// fall back to an extra pass through memory (wave-uniform branch).
+// The index arrays of H and the priors are separate __restrict__ kernel arguments: only then can
+// the compiler prove that the kernel's own stores do not alias them and fetch them with scalar
+// loads (they are wave-uniform); through the struct they became per-lane vector loads in front of
+// every message access.
+template <int VARIANT, int DMAX>
+__global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
+                                                        const int32_t* __restrict__ g_row_ptr,
+                                                        const int32_t* __restrict__ g_col_idx,
+                                                        const int32_t* __restrict__ g_col_ptr,
+                                                        const int32_t* __restrict__ g_col_edge,
+                                                        const double* __restrict__ g_prior)
+{
+    const long long lb = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = P.b0 + lb;
+    const bool valid = lb < P.Bc && b < P.B;
+    if (!valid) return;                      // whole trailing lanes only: no barriers in this kernel
+    const int m = P.m, n = P.n;
+    const long long Bc = P.Bc;
+    double* const Q = P.Q + lb;
+    double* const R = P.R + lb;
+    uint8_t* const cand = P.cand + lb;
+    uint8_t* const synT = P.synT + lb;
+    const bool force_full = (P.flags & 1u) != 0;
+    const double one_minus_damping = 1.0 - P.damping;
+
+    for (int c = 0; c < m; ++c) synT[(long long)c * Bc] = P.syndromes[b * m + c] & 1u;
+    for (int e = 0; e < P.E; ++e) Q[(long long)e * Bc] = g_prior[g_col_idx[e]];   // Q = prior on edges
+
+    bool frozen = false;
+    int it = 0;
+    for (; it < P.max_iter; ++it) {
+        // ---- check step ---------------------------------------------------------------------
+        // The next row's Q values are requested before the current row's ~500 FP64 instructions
+        // run, so their HBM latency is covered by arithmetic (software pipelining; rows longer
+        // than DMAX take the plain path below).
+        double qn[DMAX];
+        {
+            const int e0 = g_row_ptr[0], deg = g_row_ptr[1] - e0;
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j) if (j < deg) qn[j] = Q[(long long)(e0 + j) * Bc];
+        }
+        for (int c = 0; c < m; ++c) {
+            const int e0 = g_row_ptr[c], deg = g_row_ptr[c + 1] - e0;
+            const unsigned sbit = synT[(long long)c * Bc];
+            double q[DMAX];
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j) q[j] = qn[j];
+            if (c + 1 < m) {
+                const int f0 = g_row_ptr[c + 1], fdeg = g_row_ptr[c + 2] - f0;
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) if (j < fdeg) qn[j] = Q[(long long)(f0 + j) * Bc];
+            }
+            if (deg > DMAX) {
+                // long row: plain two-pass form (R holds the tanh values in between)
+                if constexpr (VARIANT == 2) {
+                    double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
+                    int min1_j = -1;
+                    for (int j = 0; j < deg; ++j) {
+                        const double x = Q[(long long)(e0 + j) * Bc];
+                        sprod *= x < 0.0 ? -1.0 : 1.0;
+                        const double a = __builtin_fabs(x);
+                        if (a < min1) { min1 = a; min1_j = j; }
+                    }
+                    for (int j = 0; j < deg; ++j) {
+                        const double a = __builtin_fabs(Q[(long long)(e0 + j) * Bc]);
+                        if (j != min1_j && a < min2) min2 = a;
+                    }
+                    const double as = sbit ? -P.alpha : P.alpha;
+                    for (int j = 0; j < deg; ++j) {
+                        const double x = Q[(long long)(e0 + j) * Bc];
+                        const double sg = x < 0.0 ? -1.0 : 1.0;
+                        const double mag = (__builtin_fabs(x) == min1) ? min2 : min1;
+                        R[(long long)(e0 + j) * Bc] = (as * (sprod * sg)) * mag;
+                    }
+                } else {
+                    double prod = 1.0;
+                    for (int j = 0; j < deg; ++j) {
+                        const double t = tanh_half(Q[(long long)(e0 + j) * Bc]);
+                        R[(long long)(e0 + j) * Bc] = t;
+                        prod = (j == 0) ? t : prod * t;
+                    }
+                    for (int j = 0; j < deg; ++j) {
+                        const double t = R[(long long)(e0 + j) * Bc];
+                        const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
+                        double po = div_nr(prod, ts);
+                        po = sbit ? -po : po;
+                        const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+                        R[(long long)(e0 + j) * Bc] = (VARIANT == 1) ? r * P.alpha : r;
+                    }
+                }
+                continue;
+            }
+            if constexpr (VARIANT == 2) {
+                // rework/decoding.py:28-56
+                double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
+                int min1_j = -1;
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) {
+                    if (j < deg) {
+                        sprod *= q[j] < 0.0 ? -1.0 : 1.0;
+                        const double a = __builtin_fabs(q[j]);
+                        if (a < min1) { min1 = a; min1_j = j; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) {
+                    if (j < deg) {
+                        const double a = __builtin_fabs(q[j]);
+                        if (j != min1_j && a < min2) min2 = a;
+                    }
+                }
+                const double as = sbit ? -P.alpha : P.alpha;
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) {
+                    if (j < deg) {
+                        const double sg = q[j] < 0.0 ? -1.0 : 1.0;
+                        const double mag = (__builtin_fabs(q[j]) == min1) ? min2 : min1;
+                        R[(long long)(e0 + j) * Bc] = (as * (sprod * sg)) * mag;
+                    }
+                }
+            } else {
+                // beliefPropagation.py:114-126 with the row's tanh values in registers
+                double t[DMAX];
+                double prod = 1.0;
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) {
+                    if (j < deg) {
+                        t[j] = tanh_half(q[j]);
+                        prod = (j == 0) ? t[0] : prod * t[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) {
+                    if (j < deg) {
+                        const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+                        double po = div_nr(prod, ts);
+                        po = sbit ? -po : po;
+                        const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+                        R[(long long)(e0 + j) * Bc] = (VARIANT == 1) ? r * P.alpha : r;
+                    }
+                }
+            }
+        }
+        // ---- variable step -------------------------------------------------------------------
+        // Pure streaming (3 adds per message): variables go in groups of VU with every gather of
+        // the group issued before the first add, so VU * degree loads are in flight per lane.
+        constexpr int VU = 8, DVF = 4;
+        for (int v0 = 0; v0 < n; v0 += VU) {
+            bool narrow = true;
+#pragma unroll
+            for (int u = 0; u < VU; ++u)
+                if (v0 + u < n) narrow = narrow && (g_col_ptr[v0 + u + 1] - g_col_ptr[v0 + u] <= DVF);
+            if (narrow) {
+                double r[VU][DVF];
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                    if (v0 + u < n) {
+                        const int k0 = g_col_ptr[v0 + u], deg = g_col_ptr[v0 + u + 1] - k0;
+#pragma unroll
+                        for (int k = 0; k < DVF; ++k)
+                            if (k < deg) r[u][k] = R[(long long)g_col_edge[k0 + k] * Bc];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < VU; ++u) {
+                    if (v0 + u < n) {
+                        const int v = v0 + u;
+                        const int k0 = g_col_ptr[v], deg = g_col_ptr[v + 1] - k0;
+                        double sum = 0.0;
+#pragma unroll
+                        for (int k = 0; k < DVF; ++k)
+                            if (k < deg) sum = (k == 0) ? r[u][0] : sum + r[u][k];   // ascending check order
+                        const double val = sum + g_prior[v];
+#pragma unroll
+                        for (int k = 0; k < DVF; ++k) {
+                            if (k < deg) {
+                                double* qp = Q + (long long)g_col_edge[k0 + k] * Bc;
+                                const double qnew = val - r[u][k];
+                                if constexpr (VARIANT == 0) {
+                                    *qp = qnew;
+                                } else {
+                                    const double x = P.damping * qnew + one_minus_damping * *qp;
+                                    const double y = x < -P.clip_llr ? -P.clip_llr : x;   // np.clip, NaN stays
+                                    *qp = y > P.clip_llr ? P.clip_llr : y;
+                                }
+                            }
+                        }
+                        cand[(long long)v * Bc] = val < 0.0;
+                    }
+                }
+            } else {
+                for (int v = v0; v < v0 + VU && v < n; ++v) {
+                    const int k0 = g_col_ptr[v], deg = g_col_ptr[v + 1] - k0;
+                    double sum = 0.0;
+                    for (int k = 0; k < deg; ++k) {
+                        const double rk = R[(long long)g_col_edge[k0 + k] * Bc];
+                        sum = (k == 0) ? rk : sum + rk;
+                    }
+                    const double val = sum + g_prior[v];
+                    for (int k = 0; k < deg; ++k) {
+                        const long long o = (long long)g_col_edge[k0 + k] * Bc;
+                        const double qnew = val - R[o];
+                        if constexpr (VARIANT == 0) {
+                            Q[o] = qnew;
+                        } else {
+                            const double x = P.damping * qnew + one_minus_damping * Q[o];
+                            const double y = x < -P.clip_llr ? -P.clip_llr : x;
+                            Q[o] = y > P.clip_llr ? P.clip_llr : y;
+                        }
+                    }
+                    cand[(long long)v * Bc] = val < 0.0;
+                }
+            }
+        }
+        // ---- syndrome check ------------------------------------------------------------------
+        unsigned unsat = 0;
+        if (!frozen) {
+            for (int c = 0; c < m; ++c) {
+                const int e0 = g_row_ptr[c], deg = g_row_ptr[c + 1] - e0;
+                unsigned par = synT[(long long)c * Bc];
+                if (deg <= DMAX) {
+                    unsigned bits[DMAX];
+#pragma unroll
+                    for (int j = 0; j < DMAX; ++j) if (j < deg) bits[j] = cand[(long long)g_col_idx[e0 + j] * Bc];
+#pragma unroll
+                    for (int j = 0; j < DMAX; ++j) if (j < deg) par ^= bits[j];
+                } else {
+                    for (int j = 0; j < deg; ++j) par ^= cand[(long long)g_col_idx[e0 + j] * Bc];
+                }
+                unsat |= par;
+            }
+        }
+        const bool conv = !frozen && !unsat;
+        const bool last = it == P.max_iter - 1;
+        if (conv || (last && !frozen)) {
+            // emit: values are recomputed from R (once per syndrome) instead of being stored n
+            // doubles per iteration
+            for (int v = 0; v < n; ++v) {
+                const int k0 = g_col_ptr[v], k1 = g_col_ptr[v + 1];
+                double s = 0.0;
+                for (int k = k0; k < k1; ++k) {
+                    const double rk = R[(long long)g_col_edge[k] * Bc];
+                    s = (k == k0) ? rk : s + rk;
+                }
+                const double val = s + g_prior[v];
+                if (P.llr) P.llr[b * n + v] = val;
+                if (P.hard) P.hard[b * n + v] = val < 0.0;
+            }
+            if (P.converged) P.converged[b] = conv;
+            if (P.iters) P.iters[b] = it;
+            frozen = true;
+        }
+        if (frozen && !force_full) break;     // lanes of a wave that are done idle until the last one is
+    }
+}
+
+}  // namespace qbp

@@ -165,8 +165,14 @@ def test_general_kernel_equals_fused_kernel_bitwise(name):
         b = dec.decode(syn, prior, 40, variant, **kw)
         c = dec.decode(syn, prior, 40, variant, flags=_lib.FLAG_FORCE_FULL, **kw)
         dec.set_option(_lib.OPT_FORCE_GENERIC, 0)
-        for x, y, z in zip(a, b, c):
+        dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_STREAM)     # lane per syndrome, messages in HBM
+        assert dec.info("kernel_kind") == 3
+        d = dec.decode(syn, prior, 40, variant, **kw)
+        e = dec.decode(syn, prior, 40, variant, flags=_lib.FLAG_FORCE_FULL, **kw)
+        dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
+        for x, y, z, u, w in zip(a, b, c, d, e):
             assert np.array_equal(x, y) and np.array_equal(x, z)
+            assert np.array_equal(x, u) and np.array_equal(x, w)
 
 
 @pytest.mark.parametrize("name,T,kind", [("[[144, 12, 12]]", 12, 1), ("[[288, 12, 18]]", 6, 1),
@@ -195,6 +201,11 @@ def test_large_spacetime_matrix_vs_oracle(name, T, kind):
         dec.set_option(_lib.OPT_FORCE_GENERIC, 0)
         for x, y in zip((hard, conv, iters, llr), g):
             assert np.array_equal(x, y)
+    dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_STREAM)       # and so does the streaming kernel
+    st = dec.decode(syn, prior, 50)
+    dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
+    for x, y in zip((hard, conv, iters, llr), st):
+        assert np.array_equal(x, y)
     o = oracle.decode_batch(Hst, syn, prior, 50)
     assert np.array_equal(conv, o[1]) and np.array_equal(iters, o[2]) and np.array_equal(hard, o[0])
     fast = conv & (iters <= 20)
@@ -253,6 +264,7 @@ def test_random_small_matrices_general_kernel_vs_oracle():
         syn = (err @ H.T % 2).astype(np.uint8)
         prior = np.log((1 - pv) / pv)
         dec = bp.decoder_for(H)
+        dec.set_option(_lib.OPT_KERNEL, trial % 4 if (trial % 4 != 1 or dec.info("kernel_kind") == 1) else 0)
         for variant, kw in ((_lib.SUM_PRODUCT, {}), (_lib.MIN_SUM, dict(alpha=0.75, damping=0.8, clip_llr=30.0))):
             hard, conv, iters, llr = dec.decode(syn, prior, 25, variant, **kw)
             o = oracle.decode_batch(H, syn, prior, 25, variant, **kw)

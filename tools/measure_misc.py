@@ -78,3 +78,32 @@ for force in (0, 1):
     dst.decode(sst, pst, 50, flags=_lib.FLAG_FORCE_FULL, want_llr=False)
     dt = time.perf_counter() - t0
     print(f"space-time 864x2592 {'general-H' if force else 'fused (8,4)'} kernel: {len(sst) / dt:.3e} syndromes/s forced 50")
+
+# streaming kernel (lane per syndrome, messages in HBM): device-resident timing on both matrices
+import torch
+dev = torch.device("cuda", 0)
+for label, Hm, pp, Bs in (("[[288,12,18]]", code.Hx, 0.01, 262144), ("space-time 864x2592", Hst, 0.005, 65536)):
+    d = bp.decoder_for(csr_matrix(Hm))
+    mm2, nn2 = Hm.shape
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    er = torch.rand((Bs, nn2), generator=g, device=dev) < pp
+    sy = (er.float() @ torch.from_numpy(np.asarray(Hm).T.astype(np.float32)).to(dev)).remainder_(2).to(torch.uint8)
+    pr = torch.full((nn2,), float(np.log((1 - pp) / pp)), dtype=torch.float64, device=dev)
+    hd = torch.empty((Bs, nn2), dtype=torch.uint8, device=dev); cv = torch.empty((Bs,), dtype=torch.uint8, device=dev)
+    itr = torch.empty((Bs,), dtype=torch.int32, device=dev); ll = torch.empty((Bs, nn2), dtype=torch.float64, device=dev)
+    stq = torch.cuda.current_stream(dev)
+    E2 = int(np.asarray(Hm).sum())
+    d.set_option(_lib.OPT_FORCE_GENERIC, 0)
+    for kern, name in ((_lib.KERNEL_STREAM, "streaming"), (_lib.KERNEL_GENERAL, "general-H"), (_lib.KERNEL_AUTO, "default")):
+        d.set_option(_lib.OPT_KERNEL, kern)
+        def run():
+            d.decode_device(sy.data_ptr(), pr.data_ptr(), Bs, 50, 0, 1.0, 1.0, 20.0, _lib.FLAG_FORCE_FULL,
+                            hd.data_ptr(), cv.data_ptr(), itr.data_ptr(), ll.data_ptr(), stq.cuda_stream)
+        run(); torch.cuda.synchronize()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(); b_.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b_)
+        alg = Bs * 50 * 4 * E2 * 8
+        print(f"{label} {name} kernel (kind {d.info('kernel_kind')}): {Bs / ms * 1e3:.3e} syndromes/s forced 50, "
+              f"{ms:.1f} ms, algorithmic message traffic {alg / ms / 1e9:.2f} TB/s")
+    d.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
