@@ -495,11 +495,16 @@ static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double
         const long long lanes = std::min<long long>(Bc, B - b0);
         const unsigned grid = (unsigned)((lanes + 255) / 256);
         h->last_threads = 256; h->last_lds = 0; h->last_grid = (int)grid;
+        // rows of at most 6 entries (every code of codes/) use the 6-register instantiation
+        const bool narrow = h->max_row_deg <= 6;
+#define QBP_STREAM_LAUNCH(V, D) hipLaunchKernelGGL((qbp::bp_stream_kernel<V, D>), dim3(grid), dim3(256), 0, s, P, \
+                                                   P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior)
         switch (variant) {
-            case QBP_SUM_PRODUCT: hipLaunchKernelGGL((qbp::bp_stream_kernel<0, 8>), dim3(grid), dim3(256), 0, s, P, P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior); break;
-            case QBP_DAMPED_SP:   hipLaunchKernelGGL((qbp::bp_stream_kernel<1, 8>), dim3(grid), dim3(256), 0, s, P, P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior); break;
-            default:              hipLaunchKernelGGL((qbp::bp_stream_kernel<2, 8>), dim3(grid), dim3(256), 0, s, P, P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior); break;
+            case QBP_SUM_PRODUCT: if (narrow) QBP_STREAM_LAUNCH(0, 6); else QBP_STREAM_LAUNCH(0, 8); break;
+            case QBP_DAMPED_SP:   if (narrow) QBP_STREAM_LAUNCH(1, 6); else QBP_STREAM_LAUNCH(1, 8); break;
+            default:              if (narrow) QBP_STREAM_LAUNCH(2, 6); else QBP_STREAM_LAUNCH(2, 8); break;
         }
+#undef QBP_STREAM_LAUNCH
         HIP_TRY(hipGetLastError());
     }
     return QBP_OK;

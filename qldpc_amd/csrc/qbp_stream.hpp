@@ -20,6 +20,10 @@
 
 #include "qbp_math.hpp"
 
+#ifndef QBP_STREAM_VU
+#define QBP_STREAM_VU 8
+#endif
+
 namespace qbp {
 
 struct StreamParams {
@@ -65,6 +69,10 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
     const bool valid = lb < P.Bc && b < P.B;
     if (!valid) return;                      // whole trailing lanes only: no barriers in this kernel
     const int m = P.m, n = P.n;
+    // Workspace layout [edge][syndrome]: neighbouring wavefronts touch neighbouring 512-byte lines,
+    // which spreads every access wave over the HBM channels.  (A tile-major layout
+    // [64 syndromes][edge][lane] was 10 % slower: all waves then walk their tiles at the same
+    // offset and collide on the same channels.)
     const long long Bc = P.Bc;
     double* const Q = P.Q + lb;
     double* const R = P.R + lb;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
         // ---- variable step -------------------------------------------------------------------
         // Pure streaming (3 adds per message): variables go in groups of VU with every gather of
         // the group issued before the first add, so VU * degree loads are in flight per lane.
-        constexpr int VU = 8, DVF = 4;
+        constexpr int VU = QBP_STREAM_VU, DVF = 4;
         for (int v0 = 0; v0 < n; v0 += VU) {
             bool narrow = true;
 #pragma unroll
