@@ -194,7 +194,7 @@ def main():
                       "source": "profiles/r01_stream_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, 262144-syndrome launch)"}
             except Exception:
                 tr = None
-        streamed = {"kernel": "qbp::bp_stream_kernel<0,8>", "value": world * B * 3 / wall_s,
+        streamed = {"kernel": "qbp::bp_stream_kernel<0,6>", "value": world * B * 3 / wall_s,
                     "unit": "syndromes/s", "kernel_ms": kernel_ms_s,
                     "roofline": {"bound": "hbm", "achieved": ach_s / 1e9, "peak": HBM_PEAK / 1e9,
                                  "unit": "GB/s", "frac": ach_s / HBM_PEAK, "traffic": tr},
