@@ -167,8 +167,9 @@ enum {
     QBP_OPT_KERNEL = 5,          /* 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome),
                                     3 streaming (lane per syndrome, messages in HBM)          */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
-    QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 fused on-chip, 2 generic */
-    QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109
+    QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 on-chip, 2 general-H, 3 streaming */
+    QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109,
+    QBP_INFO_LAST_KERNEL = 110 /* kernel of the last decode launch: 1 on-chip, 2 general-H, 3 streaming */
 };
 int qbp_set_option(qbp_handle* h, int32_t option, int64_t value);
 int64_t qbp_get_info(qbp_handle* h, int32_t what);

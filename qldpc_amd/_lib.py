@@ -26,7 +26,7 @@ COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "in
 OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_FORCE_GENERIC, OPT_KERNEL = 1, 2, 4, 5
 KERNEL_AUTO, KERNEL_ON_CHIP, KERNEL_GENERAL, KERNEL_STREAM = 0, 1, 2, 3
 INFO = dict(m=100, n=101, edges=102, max_row_deg=103, max_col_deg=104, kernel_kind=105,
-            threads=106, lds_bytes=107, grid=108, num_cu=109)
+            threads=106, lds_bytes=107, grid=108, num_cu=109, last_kernel=110)
 
 # every symbol include/qbp.h declares: (restype, argtypes)
 _VP = C.c_void_p

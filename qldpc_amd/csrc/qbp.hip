@@ -82,7 +82,7 @@ struct qbp_handle {
     // options
     int opt_slots = 0, opt_blocks_per_cu = 0;
     // last launch configuration (introspection)
-    int last_threads = 0, last_lds = 0, last_grid = 0;
+    int last_threads = 0, last_lds = 0, last_grid = 0, last_kernel = 0;
     // scratch for the host-pointer entry points
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> d_syn, d_hard, d_conv;
@@ -528,6 +528,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     if (h->opt_force_generic) kernel = 2;
     if (kernel == 1 && !h->fused_ok) return fail(QBP_E_UNSUPPORTED, "H does not fit the on-chip kernel");
     if (kernel == 0) kernel = h->fused_ok ? 1 : (B >= 16384 ? 3 : 2);
+    h->last_kernel = kernel;
     if (kernel == 3)
         return stream_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr, flags,
                              d_hard, d_converged, d_iters, d_llr, s);
@@ -877,10 +878,11 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
         case QBP_INFO_EDGES: return h->E;
         case QBP_INFO_MAX_ROW_DEG: return h->max_row_deg;
         case QBP_INFO_MAX_COL_DEG: return h->max_col_deg;
-        case QBP_INFO_KERNEL_KIND:
+        case QBP_INFO_KERNEL_KIND:   // the kernel a decode call would use (small batch), see also ..._LAST
             if (h->opt_force_generic) return 2;
             if (h->opt_kernel) return h->opt_kernel;
             return h->fused_ok ? 1 : 2;   // (auto picks 3 for batches >= 16384 when not on-chip)
+        case QBP_INFO_LAST_KERNEL: return h->last_kernel;
         case QBP_INFO_THREADS: return h->last_threads;
         case QBP_INFO_LDS_BYTES: return h->last_lds;
         case QBP_INFO_GRID: return h->last_grid;

@@ -203,6 +203,7 @@ def test_large_spacetime_matrix_vs_oracle(name, T, kind):
             assert np.array_equal(x, y)
     dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_STREAM)       # and so does the streaming kernel
     st = dec.decode(syn, prior, 50)
+    assert dec.info("last_kernel") == 3
     dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
     for x, y in zip((hard, conv, iters, llr), st):
         assert np.array_equal(x, y)
