@@ -69,12 +69,17 @@ __global__ __launch_bounds__(256) void bp_generic_kernel(const GenericParams P)
                 if constexpr (VARIANT == 2) {
                     double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
                     int min1_e = -1;
+                    bool anynan = false;
                     for (int e = b0; e < e1; ++e) {
                         const double q = Q[e];
                         sprod *= q < 0.0 ? -1.0 : 1.0;
+                        anynan |= q != q;
                         const double a = __builtin_fabs(q);
                         if (a < min1) { min1 = a; min1_e = e; }
                     }
+                    // np.sign(nan) = nan: one NaN message makes the row's sign product, hence every
+                    // R of the row, NaN (rework/decoding.py:28-35; inf - inf with infinite priors)
+                    if (anynan) sprod = __builtin_nan("");
                     for (int e = b0; e < e1; ++e) {
                         const double a = __builtin_fabs(Q[e]);
                         if (e != min1_e && a < min2) min2 = a;

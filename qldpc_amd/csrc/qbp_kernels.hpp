@@ -302,13 +302,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 // rework/decoding.py:28-56
                 double sprod = 1.0, min1 = __builtin_inf();
                 int min1_j = 0;
+                bool anynan = false;
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
                     const double s = Q[j] < 0.0 ? -1.0 : 1.0;   // sign, 0 -> +1, padding +1
                     sprod *= s;
+                    anynan |= Q[j] != Q[j];
                     const double a = __builtin_fabs(Q[j]);
                     if (a < min1) { min1 = a; min1_j = j; }       // first occurrence
                 }
+                // np.sign(nan) = nan: one NaN message (inf - inf with infinite priors) makes the
+                // row's sign product, hence every R of the row, NaN
+                if (anynan) sprod = __builtin_nan("");
                 double min2 = __builtin_inf();
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {

@@ -113,12 +113,15 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
                 if constexpr (VARIANT == 2) {
                     double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
                     int min1_j = -1;
+                    bool anynan = false;
                     for (int j = 0; j < deg; ++j) {
                         const double x = Q[(long long)(e0 + j) * Bc];
                         sprod *= x < 0.0 ? -1.0 : 1.0;
+                        anynan |= x != x;
                         const double a = __builtin_fabs(x);
                         if (a < min1) { min1 = a; min1_j = j; }
                     }
+                    if (anynan) sprod = __builtin_nan("");   // np.sign(nan) = nan: whole row NaN
                     for (int j = 0; j < deg; ++j) {
                         const double a = __builtin_fabs(Q[(long long)(e0 + j) * Bc]);
                         if (j != min1_j && a < min2) min2 = a;
@@ -152,14 +155,17 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
                 // rework/decoding.py:28-56
                 double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
                 int min1_j = -1;
+                bool anynan = false;
 #pragma unroll
                 for (int j = 0; j < DMAX; ++j) {
                     if (j < deg) {
                         sprod *= q[j] < 0.0 ? -1.0 : 1.0;
+                        anynan |= q[j] != q[j];
                         const double a = __builtin_fabs(q[j]);
                         if (a < min1) { min1 = a; min1_j = j; }
                     }
                 }
+                if (anynan) sprod = __builtin_nan("");       // np.sign(nan) = nan: whole row NaN
 #pragma unroll
                 for (int j = 0; j < DMAX; ++j) {
                     if (j < deg) {
