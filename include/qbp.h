@@ -14,6 +14,9 @@
  *     points take device pointers, enqueue on the given HIP stream and return immediately;
  *   - a handle owns the device copies of the code's tables, is bound to one device and is not
  *     thread-safe (one handle per thread / GPU); distinct handles are independent;
+ *   - launches of ONE handle share its work counter and scratch workspaces: "_device" calls on
+ *     the same handle must be ordered on one stream (or by events); to overlap launches on
+ *     several streams use one handle per stream;
  *   - there is NO CPU fallback: without a usable HIP device qbp_create fails with
  *     QBP_E_NO_DEVICE.
  */

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -30,6 +31,13 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+
+// No C++ exception crosses the C ABI: every entry point that can allocate host memory is a
+// function-try-block ending in QBP_ABI_CATCH.
+#define QBP_ABI_CATCH                                                                      \
+    catch (const std::bad_alloc&) { return fail(QBP_E_NOMEM, "out of host memory"); }     \
+    catch (const std::exception& ex) { return fail(QBP_E_INVALID, "internal error: %s", ex.what()); } \
+    catch (...) { return fail(QBP_E_INVALID, "internal error"); }
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
@@ -67,6 +75,7 @@ struct qbp_handle {
     int device = 0;
     int m = 0, n = 0, E = 0;
     int max_row_deg = 0, max_col_deg = 0;
+    int row_regular = 0, col_regular = 0;   // common row / column weight, 0 = irregular
     int num_cu = 0;
     bool fused_ok = false;
     int dc = DC_SMALL, dv = DV_SMALL;   // instantiation used by this matrix
@@ -128,9 +137,17 @@ template <int DC, int DV, int VARIANT, bool MC, bool FORCE, int MAXT, int MINW>
 hipError_t launch_k(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
 {
     auto kern = qbp::bp_fused_kernel<DC, DV, VARIANT, MC, FORCE, MAXT, MINW>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
-    if (e != hipSuccess) return e;
+    // the dynamic-LDS limit of an instantiation is raised once per device and size (the attribute
+    // call costs a few microseconds, which matters for one-syndrome-per-call users)
+    static thread_local int lds_set[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || lds_set[dev] < cfg.lds_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) lds_set[dev] = cfg.lds_bytes;
+    }
     hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(cfg.threads), cfg.lds_bytes, stream, P);
     return hipGetLastError();
 }
@@ -172,6 +189,7 @@ size_t fused_lds_bytes(int dc, int m, int n, int S)
 // exposes it so that the CPU test-suite can check the tables).
 struct HostTables {
     int max_row = 0, max_col = 0, dc = DC_SMALL, dv = DV_SMALL;
+    int row_regular = 0, col_regular = 0;
     bool fused_ok = false, padded = false;
     std::vector<int32_t> tab_var;      // [dc][m]
     std::vector<uint16_t> tab_nbr;     // [dc][dv][m]
@@ -203,6 +221,10 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
         T.max_col = std::max(T.max_col, (int)cols[v].size());
         if (cols[v].empty()) T.iso.push_back(v);
     }
+    T.row_regular = T.max_row;
+    for (int c = 0; c < m; ++c) if (row_ptr[c + 1] - row_ptr[c] != T.max_row) T.row_regular = 0;
+    T.col_regular = T.max_col;
+    for (int v = 0; v < n; ++v) if ((int)cols[v].size() != T.max_col) T.col_regular = 0;
     if (T.max_row <= DC_SMALL && T.max_col <= DV_SMALL) { T.dc = DC_SMALL; T.dv = DV_SMALL; }
     else { T.dc = DC_WIDE; T.dv = DV_WIDE; }
     T.fused_ok = (m <= 1024) && T.max_row <= T.dc && T.max_col <= T.dv &&
@@ -308,7 +330,7 @@ const char* qbp_version(void) { return "qbp 0.1 (gfx950)"; }
 
 int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n,
                int32_t device, qbp_handle** out)
-{
+try {
     if (!out) return fail(QBP_E_INVALID, "out is null");
     *out = nullptr;
     HostTables T;
@@ -324,17 +346,22 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
         return fail(QBP_E_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
     HIP_TRY(hipSetDevice(device));
 
-    qbp_handle* h = new (std::nothrow) qbp_handle();
-    if (!h) return fail(QBP_E_NOMEM, "out of host memory");
+    struct Guard {                       // destroys a half-built handle on every early exit
+        qbp_handle* h;
+        ~Guard() { if (h) qbp_destroy(h); }
+    } guard{new qbp_handle()};
+    qbp_handle* h = guard.h;
     h->device = device; h->m = m; h->n = n; h->E = E;
     h->row_ptr.assign(row_ptr, row_ptr + m + 1);
     h->col_idx.assign(col_idx, col_idx + E);
     h->max_row_deg = T.max_row;
     h->max_col_deg = T.max_col;
+    h->row_regular = T.row_regular;
+    h->col_regular = T.col_regular;
     h->dc = T.dc; h->dv = T.dv; h->fused_ok = T.fused_ok; h->padded = T.padded;
     h->n_iso = (int)T.iso.size();
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return fail(QBP_E_HIP, "hipGetDeviceProperties failed"); }
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount;
 
     hipError_t e1 = hipSuccess;
@@ -389,18 +416,16 @@ int qbp_create(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_
     if (e1 == hipSuccess) e1 = h->d_work_counter.reserve(1);
     if (e1 == hipSuccess) e1 = h->d_fail_count.reserve(1);
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e1 != hipSuccess) {
-        int rc = fail(QBP_E_HIP, "device setup failed: %s", hipGetErrorString(e1));
-        qbp_destroy(h);
-        return rc;
-    }
+    if (e1 != hipSuccess) return fail(QBP_E_HIP, "device setup failed: %s", hipGetErrorString(e1));
+    guard.h = nullptr;
     *out = h;
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 int qbp_plan(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n, int32_t info[8],
              int32_t* tab_var, uint16_t* tab_nbr, uint32_t* tab_writer)
-{
+try {
     HostTables T;
     int rc = build_tables(row_ptr, col_idx, m, n, T);
     if (rc) return rc;
@@ -416,6 +441,7 @@ int qbp_plan(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t 
     }
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 void qbp_destroy(qbp_handle* h)
 {
@@ -478,8 +504,9 @@ static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double
     long long Bc = (long long)std::min<unsigned long long>(((unsigned long long)16 << 30) / per_lane,
                                                           (unsigned long long)B);
     Bc = std::max<long long>(256, (Bc + 255) / 256 * 256);
-    HIP_TRY(h->d_wsQ.reserve((size_t)Bc * E));
-    HIP_TRY(h->d_wsR.reserve((size_t)Bc * E));
+    const size_t msg_doubles = (size_t)Bc * E;
+    HIP_TRY(h->d_wsQ.reserve(msg_doubles));
+    HIP_TRY(h->d_wsR.reserve(msg_doubles));
     HIP_TRY(h->d_wsC.reserve((size_t)Bc * n));
     HIP_TRY(h->d_wsS.reserve((size_t)Bc * m));
     qbp::StreamParams P{};
@@ -495,15 +522,20 @@ static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double
         const long long lanes = std::min<long long>(Bc, B - b0);
         const unsigned grid = (unsigned)((lanes + 255) / 256);
         h->last_threads = 256; h->last_lds = 0; h->last_grid = (int)grid;
-        // rows of at most 6 entries (every code of codes/) use the 6-register instantiation
+        // rows of at most 6 entries (every code of codes/) use the 6-register instantiation; the
+        // (6, 3)-regular ones among them (all BB codes) the straight-line one
         const bool narrow = h->max_row_deg <= 6;
-#define QBP_STREAM_LAUNCH(V, D) hipLaunchKernelGGL((qbp::bp_stream_kernel<V, D>), dim3(grid), dim3(256), 0, s, P, \
-                                                   P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior)
+        const bool reg63 = h->row_regular == 6 && h->col_regular == 3;
+#define QBP_STREAM_LAUNCH(V, ...) hipLaunchKernelGGL((qbp::bp_stream_kernel<V, __VA_ARGS__>), dim3(grid), dim3(256), 0, s, P, \
+                                                     P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior)
+#define QBP_STREAM_PICK(V) do { if (reg63) QBP_STREAM_LAUNCH(V, 6, 3); else if (narrow) QBP_STREAM_LAUNCH(V, 6); \
+                                else QBP_STREAM_LAUNCH(V, 8); } while (0)
         switch (variant) {
-            case QBP_SUM_PRODUCT: if (narrow) QBP_STREAM_LAUNCH(0, 6); else QBP_STREAM_LAUNCH(0, 8); break;
-            case QBP_DAMPED_SP:   if (narrow) QBP_STREAM_LAUNCH(1, 6); else QBP_STREAM_LAUNCH(1, 8); break;
-            default:              if (narrow) QBP_STREAM_LAUNCH(2, 6); else QBP_STREAM_LAUNCH(2, 8); break;
+            case QBP_SUM_PRODUCT: QBP_STREAM_PICK(0); break;
+            case QBP_DAMPED_SP:   QBP_STREAM_PICK(1); break;
+            default:              QBP_STREAM_PICK(2); break;
         }
+#undef QBP_STREAM_PICK
 #undef QBP_STREAM_LAUNCH
         HIP_TRY(hipGetLastError());
     }
@@ -733,7 +765,7 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
                       int64_t trial_end, const double* d_prior, int32_t max_iter,
                       int32_t variant, double alpha, double damping, double clip_llr,
                       uint32_t flags, int64_t* d_counters, void* stream)
-{
+try {
     const int64_t T = trial_end - trial_begin;
     int rc = check_decode_args(h, T, max_iter, variant, /*need_fused=*/true);
     if (rc) return rc;
@@ -789,6 +821,7 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
     }
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, double p,
                int32_t draws, uint64_t seed, int64_t trial_begin, int64_t trial_end,
@@ -816,7 +849,7 @@ int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, do
 
 int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
                          int64_t trial_begin, int64_t T, uint8_t* errors)
-{
+try {
     int rc = check_decode_args(h, T, 1, 0, /*need_fused=*/true);
     if (rc) return rc;
     if (!errors) return fail(QBP_E_INVALID, "errors is null");
@@ -849,6 +882,7 @@ int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
 {

@@ -17,12 +17,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=262144)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--kernel", type=int, default=_lib.KERNEL_STREAM)
+ap.add_argument("--p", type=float, default=0.01)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 code = codes.load_code("[[288, 12, 18]]")
 m, n = code.Hx.shape
 E = int(code.Hx.sum())
-B, p = args.batch, 0.01
+B, p = args.batch, args.p
 g = torch.Generator(device=dev); g.manual_seed(1)
 err = torch.rand((B, n), generator=g, device=dev) < p
 syn = (err.float() @ torch.from_numpy(code.Hx.T.astype(np.float32)).to(dev)).remainder_(2).to(torch.uint8)
