@@ -75,7 +75,6 @@ struct qbp_handle {
     int device = 0;
     int m = 0, n = 0, E = 0;
     int max_row_deg = 0, max_col_deg = 0;
-    int row_regular = 0, col_regular = 0;   // common row / column weight, 0 = irregular
     int num_cu = 0;
     bool fused_ok = false;
     int dc = DC_SMALL, dv = DV_SMALL;   // instantiation used by this matrix
@@ -108,6 +107,9 @@ struct qbp_handle {
     int opt_force_generic = 0;
     int opt_kernel = 0;             // 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome), 3 streaming
     DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes
+    DevBuf<int32_t> d_srow, d_srow_e0, d_srow_deg, d_svar, d_sedge;   // weight-class tables
+    int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
+    int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
     // pinned, device-mapped staging for small host-pointer calls (zero-copy: no hipMemcpy at all)
     void* pin_host = nullptr;
     void* pin_dev = nullptr;
@@ -189,12 +191,15 @@ size_t fused_lds_bytes(int dc, int m, int n, int S)
 // exposes it so that the CPU test-suite can check the tables).
 struct HostTables {
     int max_row = 0, max_col = 0, dc = DC_SMALL, dv = DV_SMALL;
-    int row_regular = 0, col_regular = 0;
     bool fused_ok = false, padded = false;
     std::vector<int32_t> tab_var;      // [dc][m]
     std::vector<uint16_t> tab_nbr;     // [dc][dv][m]
     std::vector<uint32_t> tab_writer;  // [m]
     std::vector<int32_t> iso, col_ptr, col_edge;
+    // streaming kernel: checks / variables sorted by weight class (qbp_stream.hpp)
+    std::vector<int32_t> srow, srow_e0, srow_deg, svar, sedge;
+    int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
+    int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
 };
 
 int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, HostTables& T)
@@ -221,10 +226,6 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
         T.max_col = std::max(T.max_col, (int)cols[v].size());
         if (cols[v].empty()) T.iso.push_back(v);
     }
-    T.row_regular = T.max_row;
-    for (int c = 0; c < m; ++c) if (row_ptr[c + 1] - row_ptr[c] != T.max_row) T.row_regular = 0;
-    T.col_regular = T.max_col;
-    for (int v = 0; v < n; ++v) if ((int)cols[v].size() != T.max_col) T.col_regular = 0;
     if (T.max_row <= DC_SMALL && T.max_col <= DV_SMALL) { T.dc = DC_SMALL; T.dv = DV_SMALL; }
     else { T.dc = DC_WIDE; T.dv = DV_WIDE; }
     T.fused_ok = (m <= 1024) && T.max_row <= T.dc && T.max_col <= T.dv &&
@@ -254,6 +255,31 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
     for (int v = 0; v < n; ++v)
         for (size_t k = 0; k < cols[v].size(); ++k)
             T.col_edge[T.col_ptr[v] + k] = row_ptr[cols[v][k].first] + cols[v][k].second;
+    // weight classes of the streaming kernel: rows 0 .. 8 and > 8, columns 0 .. 4 and > 4
+    constexpr int RC = qbp::STREAM_MAX_ROW_CLASS, CC = qbp::STREAM_MAX_COL_CLASS;
+    for (int k = 0; k <= RC + 1; ++k) {
+        T.row_off[k] = (int)T.srow.size();
+        for (int c = 0; c < m; ++c) {
+            const int deg = row_ptr[c + 1] - row_ptr[c];
+            if (std::min(deg, RC + 1) != k) continue;
+            T.srow.push_back(c);
+            T.srow_e0.push_back(row_ptr[c]);
+            T.srow_deg.push_back(deg);
+        }
+    }
+    T.row_off[RC + 2] = m;
+    for (int k = 0; k <= CC + 1; ++k) {
+        T.col_off[k] = (int)T.svar.size();
+        T.col_edge_base[k] = (int)T.sedge.size();
+        for (int v = 0; v < n; ++v) {
+            if (std::min<int>((int)cols[v].size(), CC + 1) != k) continue;
+            T.svar.push_back(v);
+            if (k >= 1 && k <= CC)
+                for (int q = T.col_ptr[v]; q < T.col_ptr[v + 1]; ++q) T.sedge.push_back(T.col_edge[q]);
+        }
+    }
+    T.col_off[CC + 2] = n;
+    if (T.sedge.empty()) T.sedge.push_back(0);
     return QBP_OK;
 }
 
@@ -356,8 +382,6 @@ try {
     h->col_idx.assign(col_idx, col_idx + E);
     h->max_row_deg = T.max_row;
     h->max_col_deg = T.max_col;
-    h->row_regular = T.row_regular;
-    h->col_regular = T.col_regular;
     h->dc = T.dc; h->dv = T.dv; h->fused_ok = T.fused_ok; h->padded = T.padded;
     h->n_iso = (int)T.iso.size();
     hipDeviceProp_t prop;
@@ -379,6 +403,14 @@ try {
     up(h->d_iso, T.iso);
     up(h->d_col_ptr, T.col_ptr);
     up(h->d_col_edge, T.col_edge);
+    up(h->d_srow, T.srow);
+    up(h->d_srow_e0, T.srow_e0);
+    up(h->d_srow_deg, T.srow_deg);
+    up(h->d_svar, T.svar);
+    up(h->d_sedge, T.sedge);
+    std::copy(std::begin(T.row_off), std::end(T.row_off), h->row_off);
+    std::copy(std::begin(T.col_off), std::end(T.col_off), h->col_off);
+    std::copy(std::begin(T.col_edge_base), std::end(T.col_edge_base), h->col_edge_base);
     up(h->d_row_ptr, h->row_ptr);
     up(h->d_col_idx, h->col_idx);
     {   // OSD-0: bit-packed rows of H and its CSR
@@ -454,7 +486,8 @@ void qbp_destroy(qbp_handle* h)
     h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
     if (h->pin_host) (void)hipHostFree(h->pin_host);
     h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
-    h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release();
+    h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release(); h->d_svar.release(); h->d_sedge.release();
+    h->d_srow.release(); h->d_srow_e0.release(); h->d_srow_deg.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
@@ -511,31 +544,26 @@ static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double
     HIP_TRY(h->d_wsS.reserve((size_t)Bc * m));
     qbp::StreamParams P{};
     P.m = h->m; P.n = h->n; P.E = h->E;
-    P.row_ptr = h->d_row_ptr.p; P.col_idx = h->d_col_idx.p;
-    P.col_ptr = h->d_col_ptr.p; P.col_edge = h->d_col_edge.p;
-    P.syndromes = d_syndromes; P.prior = d_prior; P.B = B; P.Bc = Bc;
+    P.syndromes = d_syndromes; P.B = B; P.Bc = Bc;
     P.max_iter = max_iter; P.flags = flags; P.alpha = alpha; P.damping = damping; P.clip_llr = clip_llr;
     P.hard = d_hard; P.converged = d_converged; P.iters = d_iters; P.llr = d_llr;
     P.Q = h->d_wsQ.p; P.R = h->d_wsR.p; P.cand = h->d_wsC.p; P.synT = h->d_wsS.p;
+    std::copy(std::begin(h->row_off), std::end(h->row_off), P.row_off);
+    std::copy(std::begin(h->col_off), std::end(h->col_off), P.col_off);
+    std::copy(std::begin(h->col_edge_base), std::end(h->col_edge_base), P.col_edge_base);
     for (long long b0 = 0; b0 < B; b0 += Bc) {
         P.b0 = b0;
         const long long lanes = std::min<long long>(Bc, B - b0);
         const unsigned grid = (unsigned)((lanes + 255) / 256);
         h->last_threads = 256; h->last_lds = 0; h->last_grid = (int)grid;
-        // rows of at most 6 entries (every code of codes/) use the 6-register instantiation; the
-        // (6, 3)-regular ones among them (all BB codes) the straight-line one
-        const bool narrow = h->max_row_deg <= 6;
-        const bool reg63 = h->row_regular == 6 && h->col_regular == 3;
-#define QBP_STREAM_LAUNCH(V, ...) hipLaunchKernelGGL((qbp::bp_stream_kernel<V, __VA_ARGS__>), dim3(grid), dim3(256), 0, s, P, \
-                                                     P.row_ptr, P.col_idx, P.col_ptr, P.col_edge, P.prior)
-#define QBP_STREAM_PICK(V) do { if (reg63) QBP_STREAM_LAUNCH(V, 6, 3); else if (narrow) QBP_STREAM_LAUNCH(V, 6); \
-                                else QBP_STREAM_LAUNCH(V, 8); } while (0)
+#define QBP_STREAM_LAUNCH(V) hipLaunchKernelGGL((qbp::bp_stream_kernel<V>), dim3(grid), dim3(256), 0, s, P, \
+        h->d_col_idx.p, h->d_col_ptr.p, h->d_col_edge.p, d_prior, h->d_srow.p, h->d_srow_e0.p,             \
+        h->d_srow_deg.p, h->d_svar.p, h->d_sedge.p)
         switch (variant) {
-            case QBP_SUM_PRODUCT: QBP_STREAM_PICK(0); break;
-            case QBP_DAMPED_SP:   QBP_STREAM_PICK(1); break;
-            default:              QBP_STREAM_PICK(2); break;
+            case QBP_SUM_PRODUCT: QBP_STREAM_LAUNCH(0); break;
+            case QBP_DAMPED_SP:   QBP_STREAM_LAUNCH(1); break;
+            default:              QBP_STREAM_LAUNCH(2); break;
         }
-#undef QBP_STREAM_PICK
 #undef QBP_STREAM_LAUNCH
         HIP_TRY(hipGetLastError());
     }

@@ -11,6 +11,12 @@
 // variants, which also read the old Q) plus n + E bytes of hard-decision traffic: its HBM traffic
 // measured by the PMC counters IS the roofline figure, not an effective bandwidth.
 //
+// Rows and columns of H are processed by WEIGHT CLASS (rows of weight 1 .. 8, columns of weight
+// 1 .. 4; the host sorts them, build_tables in qbp.hip): within a class the weight is a
+// compile-time constant and the body is straight-line code -- no per-entry degree tests, which
+// the compiler otherwise turns into branches around every load.  Neither step depends on the
+// order in which rows (columns) are visited.  Longer rows / columns take plain loops.
+//
 // Arithmetic and order are those of the other kernels (ascending column within a row, ascending
 // check within a column), so outputs are bit-identical to theirs (tested).
 #pragma once
@@ -20,24 +26,19 @@
 
 #include "qbp_math.hpp"
 
+// variables per group of the variable step (two groups are in flight)
 #ifndef QBP_STREAM_VU
-#define QBP_STREAM_VU 8
-#endif
-// variables per group in the pipelined variable step of regular matrices
-#ifndef QBP_STREAM_VU_REG
-#define QBP_STREAM_VU_REG 4
+#define QBP_STREAM_VU 4
 #endif
 
 namespace qbp {
 
+constexpr int STREAM_MAX_ROW_CLASS = 8;   // rows of weight 1 .. 8 have their own instantiation
+constexpr int STREAM_MAX_COL_CLASS = 4;   // columns of weight 1 .. 4
+
 struct StreamParams {
     int m, n, E;
-    const int32_t* row_ptr;     // CSR
-    const int32_t* col_idx;
-    const int32_t* col_ptr;     // CSC: edge ids of each column, ascending check
-    const int32_t* col_edge;
     const uint8_t* syndromes;   // [B][m]
-    const double* prior;        // [n]
     long long B;                // syndromes in the whole call
     long long b0;               // first syndrome of this launch (chunk)
     long long Bc;               // lanes of this launch = row stride of the workspace arrays
@@ -52,23 +53,235 @@ struct StreamParams {
     double* R;                  // [E][Bc]
     uint8_t* cand;              // [n][Bc] candidate error of the current iteration
     uint8_t* synT;              // [m][Bc] syndromes, transposed once at the start
+    // Checks sorted by row weight (stable): positions [row_off[k], row_off[k + 1]) of the sorted
+    // check table hold the checks of weight k for k = 0 .. 8 and of weight > 8 for k = 9.
+    int row_off[STREAM_MAX_ROW_CLASS + 3];
+    // Variables sorted by column weight (stable): positions [col_off[k], col_off[k + 1]) hold the
+    // variables of weight k for k = 0 .. 4 and of weight > 4 for k = 5; the edges of the weight-k
+    // variables (k = 1 .. 4) are listed contiguously from col_edge_base[k] in the sorted edge table.
+    int col_off[STREAM_MAX_COL_CLASS + 3];
+    int col_edge_base[STREAM_MAX_COL_CLASS + 2];
 };
 
-// DMAX: rows / columns of at most DMAX entries keep their working values in registers; longer ones
-// fall back to an extra pass through memory (wave-uniform branch).
+// Check step for the checks of one row-weight class D (positions [begin, end) of the sorted check
+// table; srow = check index, srow_e0 = its first edge).  beliefPropagation.py:114-126 /
+// rework/decoding.py:28-56 with the row's values in registers.  The next row's Q values are
+// requested before the current row's ~90 D FP64 instructions run, so their HBM latency is covered
+// by arithmetic (software pipelining).
+template <int VARIANT, int D>
+__device__ __forceinline__ void stream_check_class(const double* Q, double* R, const uint8_t* synT,
+                                                   long long ES, long long Bc,
+                                                   const int32_t* __restrict__ srow,
+                                                   const int32_t* __restrict__ srow_e0, int begin,
+                                                   int end, double alpha)
+{
+    double qn[D];
+    {
+        const int e0 = srow_e0[begin];
+#pragma unroll
+        for (int j = 0; j < D; ++j) qn[j] = Q[(long long)(e0 + j) * ES];
+    }
+    for (int i = begin; i < end; ++i) {
+        const int e0 = srow_e0[i];
+        const unsigned sbit = synT[(long long)srow[i] * Bc];
+        double q[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) q[j] = qn[j];
+        if (i + 1 < end) {
+            const int f0 = srow_e0[i + 1];
+#pragma unroll
+            for (int j = 0; j < D; ++j) qn[j] = Q[(long long)(f0 + j) * ES];
+        }
+        if constexpr (VARIANT == 2) {
+            double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
+            int min1_j = -1;
+            bool anynan = false;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                sprod *= q[j] < 0.0 ? -1.0 : 1.0;
+                anynan |= q[j] != q[j];
+                const double a = __builtin_fabs(q[j]);
+                if (a < min1) { min1 = a; min1_j = j; }          // argmin: first occurrence
+            }
+            if (anynan) sprod = __builtin_nan("");               // np.sign(nan) = nan: whole row NaN
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double a = __builtin_fabs(q[j]);
+                if (j != min1_j && a < min2) min2 = a;
+            }
+            const double as = sbit ? -alpha : alpha;             // alpha * syndrome_sign
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double sg = q[j] < 0.0 ? -1.0 : 1.0;
+                const double mag = (__builtin_fabs(q[j]) == min1) ? min2 : min1;
+                R[(long long)(e0 + j) * ES] = (as * (sprod * sg)) * mag;
+            }
+        } else {
+            double t[D];
+            double prod = 1.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                t[j] = tanh_half(q[j]);
+                prod = (j == 0) ? t[0] : prod * t[j];            // np.prod, ascending column
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+                double po = div_nr(prod, ts);
+                po = sbit ? -po : po;
+                const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+                R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
+            }
+        }
+    }
+}
+
+// Rows longer than STREAM_MAX_ROW_CLASS: plain two-pass form (R holds the tanh values in between).
+template <int VARIANT>
+__device__ __forceinline__ void stream_check_long(const double* Q, double* R, unsigned sbit,
+                                                  long long ES, int e0, int deg, double alpha)
+{
+    if constexpr (VARIANT == 2) {
+        double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
+        int min1_j = -1;
+        bool anynan = false;
+        for (int j = 0; j < deg; ++j) {
+            const double x = Q[(long long)(e0 + j) * ES];
+            sprod *= x < 0.0 ? -1.0 : 1.0;
+            anynan |= x != x;
+            const double a = __builtin_fabs(x);
+            if (a < min1) { min1 = a; min1_j = j; }
+        }
+        if (anynan) sprod = __builtin_nan("");
+        for (int j = 0; j < deg; ++j) {
+            const double a = __builtin_fabs(Q[(long long)(e0 + j) * ES]);
+            if (j != min1_j && a < min2) min2 = a;
+        }
+        const double as = sbit ? -alpha : alpha;
+        for (int j = 0; j < deg; ++j) {
+            const double x = Q[(long long)(e0 + j) * ES];
+            const double sg = x < 0.0 ? -1.0 : 1.0;
+            const double mag = (__builtin_fabs(x) == min1) ? min2 : min1;
+            R[(long long)(e0 + j) * ES] = (as * (sprod * sg)) * mag;
+        }
+    } else {
+        double prod = 1.0;
+        for (int j = 0; j < deg; ++j) {
+            const double t = tanh_half(Q[(long long)(e0 + j) * ES]);
+            R[(long long)(e0 + j) * ES] = t;
+            prod = (j == 0) ? t : prod * t;
+        }
+        for (int j = 0; j < deg; ++j) {
+            const double t = R[(long long)(e0 + j) * ES];
+            const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
+            double po = div_nr(prod, ts);
+            po = sbit ? -po : po;
+            const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+            R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
+        }
+    }
+}
+
+// Variable step for the variables of one column-weight class D (positions [begin, end) of the
+// sorted tables): value = sum of the D messages in ascending check order + prior, Q = value - R
+// (beliefPropagation.py:129-133).  Pure streaming, 3 adds per message.  Two register sets: the
+// gathers of group g + 1 are issued BEFORE the stores of group g -- vmcnt counts loads and stores
+// in issue order, so waiting for gathers issued after a group's stores would also wait for those
+// stores to be acknowledged.  The candidate error is only stored while the syndrome is undecided
+// (once its outputs are frozen nothing reads it any more).
+template <int VARIANT, int D>
+__device__ __forceinline__ void stream_var_class(double* Q, const double* R, uint8_t* cand, long long ES,
+                                                 long long Bc, const int32_t* __restrict__ svar,
+                                                 const int32_t* __restrict__ sedge,
+                                                 const double* __restrict__ prior, int begin, int end,
+                                                 int edge_base, bool frozen, double damping,
+                                                 double one_minus_damping, double clip_llr)
+{
+    constexpr int VU = QBP_STREAM_VU;
+#define QBP_GATHER(r, i0)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < VU; ++u)                                               \
+        _Pragma("unroll") for (int k = 0; k < D; ++k)                                            \
+            r[u][k] = R[(long long)sedge[edge_base + ((i0) + u - begin) * D + k] * ES];
+#define QBP_FINISH_ONE(r, i)                                                                     \
+    {                                                                                            \
+        const int v = svar[i];                                                                   \
+        double sum = r[0];                                                                       \
+        _Pragma("unroll") for (int k = 1; k < D; ++k) sum = sum + r[k];   /* ascending check */  \
+        const double val = sum + prior[v];                                                       \
+        _Pragma("unroll") for (int k = 0; k < D; ++k) {                                          \
+            double* qp = Q + (long long)sedge[edge_base + ((i) - begin) * D + k] * ES;           \
+            const double qnew = val - r[k];                                                      \
+            if constexpr (VARIANT == 0) {                                                        \
+                *qp = qnew;                                                                      \
+            } else {                                                                             \
+                const double x = damping * qnew + one_minus_damping * *qp;                       \
+                const double y = x < -clip_llr ? -clip_llr : x;   /* np.clip, NaN stays */       \
+                *qp = y > clip_llr ? clip_llr : y;                                               \
+            }                                                                                    \
+        }                                                                                        \
+        if (!frozen) cand[(long long)v * Bc] = val < 0.0;                                        \
+    }
+#define QBP_FINISH(r, i0) _Pragma("unroll") for (int u = 0; u < VU; ++u) QBP_FINISH_ONE(r[u], (i0) + u)
+    const int main_end = begin + (end - begin) / (2 * VU) * (2 * VU);
+    if (main_end > begin) {
+        double ra[VU][D], rb[VU][D];
+        QBP_GATHER(ra, begin)
+        for (int i = begin; i < main_end; i += 2 * VU) {
+            QBP_GATHER(rb, i + VU)
+            QBP_FINISH(ra, i)
+            if (i + 2 * VU < main_end) { QBP_GATHER(ra, i + 2 * VU) }
+            QBP_FINISH(rb, i + VU)
+        }
+    }
+    for (int i = main_end; i < end; ++i) {
+        double r1[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) r1[k] = R[(long long)sedge[edge_base + (i - begin) * D + k] * ES];
+        QBP_FINISH_ONE(r1, i)
+    }
+#undef QBP_GATHER
+#undef QBP_FINISH_ONE
+#undef QBP_FINISH
+}
+
+// Parity of the candidate error against the syndrome for the checks of one row-weight class
+// (beliefPropagation.py:137-139); returns 1 if some check of the class is unsatisfied.
+template <int D>
+__device__ __forceinline__ unsigned stream_parity_class(const uint8_t* cand, const uint8_t* synT,
+                                                        long long Bc, const int32_t* __restrict__ srow,
+                                                        const int32_t* __restrict__ srow_e0,
+                                                        const int32_t* __restrict__ col_idx, int begin,
+                                                        int end)
+{
+    unsigned unsat = 0;
+    for (int i = begin; i < end; ++i) {
+        const int e0 = srow_e0[i];
+        unsigned par = synT[(long long)srow[i] * Bc];
+        unsigned bits[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) bits[j] = cand[(long long)col_idx[e0 + j] * Bc];
+#pragma unroll
+        for (int j = 0; j < D; ++j) par ^= bits[j];
+        unsat |= par;
+    }
+    return unsat;
+}
+
 // The index arrays of H and the priors are separate __restrict__ kernel arguments: only then can
 // the compiler prove that the kernel's own stores do not alias them and fetch them with scalar
-// loads (they are wave-uniform); through the struct they became per-lane vector loads in front of
-// every message access.
-// DVR > 0: H is regular -- every row has exactly DMAX entries and every column exactly DVR (the BB
-// codes of the reference: 6 and 3) -- and the body is straight-line code without degree tests.
-template <int VARIANT, int DMAX, int DVR = 0>
+// loads (they are wave-uniform); through the struct -- or through the captures of a lambda -- they
+// become per-lane vector loads with a full wait in front of every message access.
+template <int VARIANT>
 __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
-                                                        const int32_t* __restrict__ g_row_ptr,
                                                         const int32_t* __restrict__ g_col_idx,
                                                         const int32_t* __restrict__ g_col_ptr,
                                                         const int32_t* __restrict__ g_col_edge,
-                                                        const double* __restrict__ g_prior)
+                                                        const double* __restrict__ g_prior,
+                                                        const int32_t* __restrict__ g_srow,
+                                                        const int32_t* __restrict__ g_srow_e0,
+                                                        const int32_t* __restrict__ g_srow_deg,
+                                                        const int32_t* __restrict__ g_svar,
+                                                        const int32_t* __restrict__ g_sedge)
 {
     const long long lb = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long b = P.b0 + lb;
@@ -77,9 +290,7 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
     const int m = P.m, n = P.n;
     // Workspace layout [edge][syndrome]: neighbouring wavefronts touch neighbouring 512-byte lines,
     // which spreads every access wave over the HBM channels.  (A tile-major layout
-    // [64 syndromes][edge][lane] was 10 % slower: all waves then walk their tiles at the same
-    // offset and collide on the same channels.)
-    constexpr bool REG = DVR > 0;
+    // [64 syndromes][edge][lane] was 4-10 % slower, with or without padding between the tiles.)
     const long long Bc = P.Bc;
     double* const Q = P.Q + lb;
     double* const R = P.R + lb;
@@ -88,6 +299,7 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
     uint8_t* const synT = P.synT + lb;
     const bool force_full = (P.flags & 1u) != 0;
     const double one_minus_damping = 1.0 - P.damping;
+    constexpr int RC = STREAM_MAX_ROW_CLASS, CC = STREAM_MAX_COL_CLASS;
 
     for (int c = 0; c < m; ++c) synT[(long long)c * Bc] = P.syndromes[b * m + c] & 1u;
     for (int e = 0; e < P.E; ++e) Q[(long long)e * ES] = g_prior[g_col_idx[e]];   // Q = prior on edges
@@ -96,259 +308,69 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
     int it = 0;
     for (; it < P.max_iter; ++it) {
         // ---- check step ---------------------------------------------------------------------
-        // The next row's Q values are requested before the current row's ~500 FP64 instructions
-        // run, so their HBM latency is covered by arithmetic (software pipelining; rows longer
-        // than DMAX take the plain path below).
-        double qn[DMAX];
-        {
-            const int e0 = REG ? 0 : g_row_ptr[0], deg = REG ? DMAX : g_row_ptr[1] - e0;
-#pragma unroll
-            for (int j = 0; j < DMAX; ++j) if (REG || j < deg) qn[j] = Q[(long long)(e0 + j) * ES];
-        }
-        for (int c = 0; c < m; ++c) {
-            const int e0 = REG ? c * DMAX : g_row_ptr[c], deg = REG ? DMAX : g_row_ptr[c + 1] - e0;
-            const unsigned sbit = synT[(long long)c * Bc];
-            double q[DMAX];
-#pragma unroll
-            for (int j = 0; j < DMAX; ++j) q[j] = qn[j];
-            if (c + 1 < m) {
-                const int f0 = REG ? (c + 1) * DMAX : g_row_ptr[c + 1];
-                const int fdeg = REG ? DMAX : g_row_ptr[c + 2] - f0;
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j) if (REG || j < fdeg) qn[j] = Q[(long long)(f0 + j) * ES];
-            }
-            if (!REG && deg > DMAX) {
-                // long row: plain two-pass form (R holds the tanh values in between)
-                if constexpr (VARIANT == 2) {
-                    double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
-                    int min1_j = -1;
-                    bool anynan = false;
-                    for (int j = 0; j < deg; ++j) {
-                        const double x = Q[(long long)(e0 + j) * ES];
-                        sprod *= x < 0.0 ? -1.0 : 1.0;
-                        anynan |= x != x;
-                        const double a = __builtin_fabs(x);
-                        if (a < min1) { min1 = a; min1_j = j; }
-                    }
-                    if (anynan) sprod = __builtin_nan("");   // np.sign(nan) = nan: whole row NaN
-                    for (int j = 0; j < deg; ++j) {
-                        const double a = __builtin_fabs(Q[(long long)(e0 + j) * ES]);
-                        if (j != min1_j && a < min2) min2 = a;
-                    }
-                    const double as = sbit ? -P.alpha : P.alpha;
-                    for (int j = 0; j < deg; ++j) {
-                        const double x = Q[(long long)(e0 + j) * ES];
-                        const double sg = x < 0.0 ? -1.0 : 1.0;
-                        const double mag = (__builtin_fabs(x) == min1) ? min2 : min1;
-                        R[(long long)(e0 + j) * ES] = (as * (sprod * sg)) * mag;
-                    }
-                } else {
-                    double prod = 1.0;
-                    for (int j = 0; j < deg; ++j) {
-                        const double t = tanh_half(Q[(long long)(e0 + j) * ES]);
-                        R[(long long)(e0 + j) * ES] = t;
-                        prod = (j == 0) ? t : prod * t;
-                    }
-                    for (int j = 0; j < deg; ++j) {
-                        const double t = R[(long long)(e0 + j) * ES];
-                        const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
-                        double po = div_nr(prod, ts);
-                        po = sbit ? -po : po;
-                        const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
-                        R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * P.alpha : r;
-                    }
-                }
-                continue;
-            }
-            if constexpr (VARIANT == 2) {
-                // rework/decoding.py:28-56
-                double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
-                int min1_j = -1;
-                bool anynan = false;
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j) {
-                    if (REG || j < deg) {
-                        sprod *= q[j] < 0.0 ? -1.0 : 1.0;
-                        anynan |= q[j] != q[j];
-                        const double a = __builtin_fabs(q[j]);
-                        if (a < min1) { min1 = a; min1_j = j; }
-                    }
-                }
-                if (anynan) sprod = __builtin_nan("");       // np.sign(nan) = nan: whole row NaN
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j) {
-                    if (REG || j < deg) {
-                        const double a = __builtin_fabs(q[j]);
-                        if (j != min1_j && a < min2) min2 = a;
-                    }
-                }
-                const double as = sbit ? -P.alpha : P.alpha;
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j) {
-                    if (REG || j < deg) {
-                        const double sg = q[j] < 0.0 ? -1.0 : 1.0;
-                        const double mag = (__builtin_fabs(q[j]) == min1) ? min2 : min1;
-                        R[(long long)(e0 + j) * ES] = (as * (sprod * sg)) * mag;
-                    }
-                }
-            } else {
-                // beliefPropagation.py:114-126 with the row's tanh values in registers
-                double t[DMAX];
-                double prod = 1.0;
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j) {
-                    if (REG || j < deg) {
-                        t[j] = tanh_half(q[j]);
-                        prod = (j == 0) ? t[0] : prod * t[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j) {
-                    if (REG || j < deg) {
-                        const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
-                        double po = div_nr(prod, ts);
-                        po = sbit ? -po : po;
-                        const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
-                        R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * P.alpha : r;
-                    }
-                }
-            }
-        }
+#define QBP_ROW_CLASS(D)                                                                         \
+        if (P.row_off[D + 1] > P.row_off[D])                                                     \
+            stream_check_class<VARIANT, D>(Q, R, synT, ES, Bc, g_srow, g_srow_e0, P.row_off[D],  \
+                                           P.row_off[D + 1], P.alpha);
+        QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
+        QBP_ROW_CLASS(5) QBP_ROW_CLASS(6) QBP_ROW_CLASS(7) QBP_ROW_CLASS(8)
+#undef QBP_ROW_CLASS
+        for (int i = P.row_off[RC + 1]; i < P.row_off[RC + 2]; ++i)
+            stream_check_long<VARIANT>(Q, R, synT[(long long)g_srow[i] * Bc], ES, g_srow_e0[i],
+                                       g_srow_deg[i], P.alpha);
+
         // ---- variable step -------------------------------------------------------------------
-        // Pure streaming (3 adds per message): variables go in groups of VU with every gather of
-        // the group issued before the first add, so VU * degree loads are in flight per lane.  The
-        // candidate error is only stored while the syndrome is still undecided (once its outputs
-        // are frozen nothing reads it any more).
-        constexpr int VU = REG ? QBP_STREAM_VU_REG : QBP_STREAM_VU, DVF = REG ? DVR : 4;
-        int v_begin = 0;
-        if constexpr (REG) {
-            // Two register sets: the gathers of group g + 1 are issued BEFORE the stores of group g.
-            // (vmcnt counts loads and stores in issue order, so waiting for gathers that were
-            // issued after a group's stores also waits for those stores to be acknowledged.)
-#define QBP_GATHER(r, v0_)                                                                     \
-            _Pragma("unroll") for (int u = 0; u < VU; ++u)                                     \
-                _Pragma("unroll") for (int k = 0; k < DVF; ++k)                                \
-                    r[u][k] = R[(long long)g_col_edge[((v0_) + u) * DVF + k] * ES];
-#define QBP_FINISH(r, v0_)                                                                     \
-            _Pragma("unroll") for (int u = 0; u < VU; ++u) {                                   \
-                const int v = (v0_) + u;                                                       \
-                double sum = r[u][0];                                                          \
-                _Pragma("unroll") for (int k = 1; k < DVF; ++k) sum = sum + r[u][k];           \
-                const double val = sum + g_prior[v];                                           \
-                _Pragma("unroll") for (int k = 0; k < DVF; ++k) {                              \
-                    double* qp = Q + (long long)g_col_edge[v * DVF + k] * ES;                  \
-                    const double qnew = val - r[u][k];                                         \
-                    if constexpr (VARIANT == 0) {                                              \
-                        *qp = qnew;                                                            \
-                    } else {                                                                   \
-                        const double x = P.damping * qnew + one_minus_damping * *qp;           \
-                        const double y = x < -P.clip_llr ? -P.clip_llr : x;                    \
-                        *qp = y > P.clip_llr ? P.clip_llr : y;                                 \
-                    }                                                                          \
-                }                                                                              \
-                if (!frozen) cand[(long long)v * Bc] = val < 0.0;                              \
+        if (!frozen)
+            for (int i = P.col_off[0]; i < P.col_off[1]; ++i) {        // variables without checks
+                const int v = g_svar[i];
+                cand[(long long)v * Bc] = g_prior[v] < 0.0;
             }
-            const int n_main = n - n % (2 * VU);
-            if (n_main > 0) {
-                double ra[VU][DVF], rb[VU][DVF];
-                QBP_GATHER(ra, 0)
-                for (int v0 = 0; v0 < n_main; v0 += 2 * VU) {
-                    QBP_GATHER(rb, v0 + VU)
-                    QBP_FINISH(ra, v0)
-                    if (v0 + 2 * VU < n_main) { QBP_GATHER(ra, v0 + 2 * VU) }
-                    QBP_FINISH(rb, v0 + VU)
+#define QBP_COL_CLASS(D)                                                                         \
+        if (P.col_off[D + 1] > P.col_off[D])                                                     \
+            stream_var_class<VARIANT, D>(Q, R, cand, ES, Bc, g_svar, g_sedge, g_prior, P.col_off[D], \
+                                         P.col_off[D + 1], P.col_edge_base[D], frozen, P.damping, \
+                                         one_minus_damping, P.clip_llr);
+        QBP_COL_CLASS(1) QBP_COL_CLASS(2) QBP_COL_CLASS(3) QBP_COL_CLASS(4)
+#undef QBP_COL_CLASS
+        for (int i = P.col_off[CC + 1]; i < P.col_off[CC + 2]; ++i) {   // columns of weight > 4
+            const int v = g_svar[i];
+            const int k0 = g_col_ptr[v], deg = g_col_ptr[v + 1] - k0;
+            double sum = 0.0;
+            for (int k = 0; k < deg; ++k) {
+                const double rk = R[(long long)g_col_edge[k0 + k] * ES];
+                sum = (k == 0) ? rk : sum + rk;
+            }
+            const double val = sum + g_prior[v];
+            for (int k = 0; k < deg; ++k) {
+                const long long o = (long long)g_col_edge[k0 + k] * ES;
+                const double qnew = val - R[o];
+                if constexpr (VARIANT == 0) {
+                    Q[o] = qnew;
+                } else {
+                    const double x = P.damping * qnew + one_minus_damping * Q[o];
+                    const double y = x < -P.clip_llr ? -P.clip_llr : x;
+                    Q[o] = y > P.clip_llr ? P.clip_llr : y;
                 }
             }
-            v_begin = n_main;
-#undef QBP_GATHER
-#undef QBP_FINISH
+            if (!frozen) cand[(long long)v * Bc] = val < 0.0;
         }
-        for (int v0 = v_begin; v0 < n; v0 += VU) {
-            bool narrow = true;
-            if constexpr (!REG) {
-#pragma unroll
-                for (int u = 0; u < VU; ++u)
-                    if (v0 + u < n) narrow = narrow && (g_col_ptr[v0 + u + 1] - g_col_ptr[v0 + u] <= DVF);
-            }
-            if (narrow) {
-                double r[VU][DVF];
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                    if (v0 + u < n) {
-                        const int k0 = REG ? (v0 + u) * DVF : g_col_ptr[v0 + u];
-                        const int deg = REG ? DVF : g_col_ptr[v0 + u + 1] - k0;
-#pragma unroll
-                        for (int k = 0; k < DVF; ++k)
-                            if (REG || k < deg) r[u][k] = R[(long long)g_col_edge[k0 + k] * ES];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < VU; ++u) {
-                    if (v0 + u < n) {
-                        const int v = v0 + u;
-                        const int k0 = REG ? v * DVF : g_col_ptr[v];
-                        const int deg = REG ? DVF : g_col_ptr[v + 1] - k0;
-                        double sum = 0.0;
-#pragma unroll
-                        for (int k = 0; k < DVF; ++k)
-                            if (REG || k < deg) sum = (k == 0) ? r[u][0] : sum + r[u][k];   // ascending check order
-                        const double val = sum + g_prior[v];
-#pragma unroll
-                        for (int k = 0; k < DVF; ++k) {
-                            if (REG || k < deg) {
-                                double* qp = Q + (long long)g_col_edge[k0 + k] * ES;
-                                const double qnew = val - r[u][k];
-                                if constexpr (VARIANT == 0) {
-                                    *qp = qnew;
-                                } else {
-                                    const double x = P.damping * qnew + one_minus_damping * *qp;
-                                    const double y = x < -P.clip_llr ? -P.clip_llr : x;   // np.clip, NaN stays
-                                    *qp = y > P.clip_llr ? P.clip_llr : y;
-                                }
-                            }
-                        }
-                        if (!frozen) cand[(long long)v * Bc] = val < 0.0;
-                    }
-                }
-            } else {
-                for (int v = v0; v < v0 + VU && v < n; ++v) {
-                    const int k0 = g_col_ptr[v], deg = g_col_ptr[v + 1] - k0;
-                    double sum = 0.0;
-                    for (int k = 0; k < deg; ++k) {
-                        const double rk = R[(long long)g_col_edge[k0 + k] * ES];
-                        sum = (k == 0) ? rk : sum + rk;
-                    }
-                    const double val = sum + g_prior[v];
-                    for (int k = 0; k < deg; ++k) {
-                        const long long o = (long long)g_col_edge[k0 + k] * ES;
-                        const double qnew = val - R[o];
-                        if constexpr (VARIANT == 0) {
-                            Q[o] = qnew;
-                        } else {
-                            const double x = P.damping * qnew + one_minus_damping * Q[o];
-                            const double y = x < -P.clip_llr ? -P.clip_llr : x;
-                            Q[o] = y > P.clip_llr ? P.clip_llr : y;
-                        }
-                    }
-                    if (!frozen) cand[(long long)v * Bc] = val < 0.0;
-                }
-            }
-        }
+
         // ---- syndrome check ------------------------------------------------------------------
         unsigned unsat = 0;
         if (!frozen) {
-            for (int c = 0; c < m; ++c) {
-                const int e0 = REG ? c * DMAX : g_row_ptr[c], deg = REG ? DMAX : g_row_ptr[c + 1] - e0;
-                unsigned par = synT[(long long)c * Bc];
-                if (REG || deg <= DMAX) {
-                    unsigned bits[DMAX];
-#pragma unroll
-                    for (int j = 0; j < DMAX; ++j) if (REG || j < deg) bits[j] = cand[(long long)g_col_idx[e0 + j] * Bc];
-#pragma unroll
-                    for (int j = 0; j < DMAX; ++j) if (REG || j < deg) par ^= bits[j];
-                } else {
-                    for (int j = 0; j < deg; ++j) par ^= cand[(long long)g_col_idx[e0 + j] * Bc];
-                }
+            for (int i = P.row_off[0]; i < P.row_off[1]; ++i)           // checks without variables
+                unsat |= synT[(long long)g_srow[i] * Bc];
+#define QBP_ROW_CLASS(D)                                                                         \
+            if (P.row_off[D + 1] > P.row_off[D])                                                 \
+                unsat |= stream_parity_class<D>(cand, synT, Bc, g_srow, g_srow_e0, g_col_idx,    \
+                                                P.row_off[D], P.row_off[D + 1]);
+            QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
+            QBP_ROW_CLASS(5) QBP_ROW_CLASS(6) QBP_ROW_CLASS(7) QBP_ROW_CLASS(8)
+#undef QBP_ROW_CLASS
+            for (int i = P.row_off[RC + 1]; i < P.row_off[RC + 2]; ++i) {
+                const int e0 = g_srow_e0[i], deg = g_srow_deg[i];
+                unsigned par = synT[(long long)g_srow[i] * Bc];
+                for (int j = 0; j < deg; ++j) par ^= cand[(long long)g_col_idx[e0 + j] * Bc];
                 unsat |= par;
             }
         }
