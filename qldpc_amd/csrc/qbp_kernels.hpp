@@ -424,30 +424,38 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             const bool last = it == max_iter - 1;
             if (!frozen && (conv || last)) {
                 if constexpr (MC) {
-                    if (COLD(fail_list) != nullptr && !conv) {
+                    const ColdArgs ca = cold_args();     // one read of the cold arguments per emission
+                    const long long row = b * ca->n;
+                    const int n_iso = ca->n_iso;
+                    if (ca->fail_list != nullptr && !conv) {
                         // BP failed: leave the trial to the OSD kernel (record indexed by b)
-                        COLD(fail_syn)[b * m + c] = (uint8_t)sbit;
+                        double* const f_llr = ca->fail_llr;
+                        uint8_t* const f_hard = ca->fail_hard;
+                        uint8_t* const f_err = ca->fail_err;
+                        ca->fail_syn[b * m + c] = (uint8_t)sbit;
 #pragma unroll
                         for (int j = 0; j < DC; ++j) {
                             if ((wmask >> j) & 1u) {
-                                const long long o = b * COLD(n) + var_lds[j * m + c];
-                                COLD(fail_llr)[o] = val[j];
-                                COLD(fail_hard)[o] = (uint8_t)(val[j] < 0.0);
-                                COLD(fail_err)[o] = (uint8_t)((ebits >> j) & 1u);
+                                const long long o = row + var_lds[j * m + c];
+                                f_llr[o] = val[j];
+                                f_hard[o] = (uint8_t)(val[j] < 0.0);
+                                f_err[o] = (uint8_t)((ebits >> j) & 1u);
                             }
                         }
-                        for (int i = c; i < COLD(n_iso); i += m) {
+                        for (int i = c; i < n_iso; i += m) {
                             const int v = COLD(iso_vars)[i];
-                            const long long o = b * COLD(n) + v;
-                            COLD(fail_llr)[o] = COLD(prior)[v];
-                            COLD(fail_hard)[o] = (uint8_t)(COLD(prior)[v] < 0.0);
-                            COLD(fail_err)[o] = err_lds[v];
+                            const double pv = COLD(prior)[v];
+                            f_llr[row + v] = pv;
+                            f_hard[row + v] = (uint8_t)(pv < 0.0);
+                            f_err[row + v] = err_lds[v];
                         }
-                        if (c == 0) COLD(fail_list)[atomicAdd(COLD(fail_count), 1ull)] = b;
+                        if (c == 0) ca->fail_list[atomicAdd(ca->fail_count, 1ull)] = b;
                     } else {
                     unsigned long long lm = 0ull;
                     int ew = 0;
                     unsigned df = 0;
+                    const unsigned long long* const lx = ca->lx_cols;
+                    uint8_t* const e_out = ca->errors_out;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         if ((wmask >> j) & 1u) {
@@ -456,18 +464,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                             ew += (int)e;
                             df |= res;
                             const int v = var_lds[j * m + c];
-                            if (res) lm ^= COLD(lx_cols)[v];
-                            if (COLD(errors_out)) COLD(errors_out)[b * COLD(n) + v] = (uint8_t)e;
+                            if (res) lm ^= lx[v];
+                            if (e_out) e_out[row + v] = (uint8_t)e;
                         }
                     }
-                    for (int i = c; i < COLD(n_iso); i += m) {
+                    for (int i = c; i < n_iso; i += m) {
                         const int v = COLD(iso_vars)[i];
                         const unsigned e = err_lds[v];
                         const unsigned res = (COLD(prior)[v] < 0.0 ? 1u : 0u) ^ e;
                         ew += (int)e;
                         df |= res;
-                        if (res) lm ^= COLD(lx_cols)[v];
-                        if (COLD(errors_out)) COLD(errors_out)[b * COLD(n) + v] = (uint8_t)e;
+                        if (res) lm ^= lx[v];
+                        if (e_out) e_out[row + v] = (uint8_t)e;
                     }
                     if (lm) atomicXor(&mc_lmask[slot], lm);
                     if (ew) atomicAdd(&mc_weight[slot], ew);
@@ -475,23 +483,30 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     }
                     if (c == 0) { mc_pending = true; mc_pending_conv = conv; mc_pending_it = it; }
                 } else {
+                    // one read of the output pointers per emission (adjacent kernel arguments: a
+                    // single scalar load), not one per use
+                    const ColdArgs ca = cold_args();
+                    double* const o_llr = ca->llr;
+                    uint8_t* const o_hard = ca->hard;
+                    const long long row = b * ca->n;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         if ((wmask >> j) & 1u) {
-                            const long long o = b * COLD(n) + var_lds[j * m + c];
-                            if (COLD(llr)) COLD(llr)[o] = val[j];
-                            if (COLD(hard)) COLD(hard)[o] = (uint8_t)(val[j] < 0.0);
+                            const long long o = row + var_lds[j * m + c];
+                            if (o_llr) o_llr[o] = val[j];
+                            if (o_hard) o_hard[o] = (uint8_t)(val[j] < 0.0);
                         }
                     }
-                    for (int i = c; i < COLD(n_iso); i += m) {
+                    const int n_iso = ca->n_iso;
+                    for (int i = c; i < n_iso; i += m) {
                         const int v = COLD(iso_vars)[i];
                         const double pv = COLD(prior)[v];
-                        if (COLD(llr)) COLD(llr)[b * COLD(n) + v] = pv;
-                        if (COLD(hard)) COLD(hard)[b * COLD(n) + v] = pv < 0.0;
+                        if (o_llr) o_llr[row + v] = pv;
+                        if (o_hard) o_hard[row + v] = pv < 0.0;
                     }
                     if (c == 0) {
-                        if (COLD(converged)) COLD(converged)[b] = conv;
-                        if (COLD(iters)) COLD(iters)[b] = it;
+                        if (ca->converged) ca->converged[b] = conv;
+                        if (ca->iters) ca->iters[b] = it;
                     }
                 }
             }
