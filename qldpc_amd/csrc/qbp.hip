@@ -499,8 +499,12 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
                           unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
                           double* d_llr, double* d_dump, int dump_iter, double dump_div, hipStream_t s)
 {
-    // general-H kernel: one workgroup per syndrome, messages in a global workspace
-    const int grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * 4));
+    // general-H kernel: one workgroup per syndrome, messages in a global workspace.  Batches that
+    // cannot fill the chip with 256-thread workgroups get wider ones (latency of a single decode
+    // of a large matrix: checks / variables per thread shrink 4x).
+    const bool wide = B < (long long)h->num_cu * 2;
+    const int threads = wide ? std::min(1024, std::max(256, (std::max(h->m, 64) + 63) / 64 * 64)) : 256;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * (wide ? 1 : 4)));
     const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
     HIP_TRY(h->d_wsQ.reserve((size_t)grid * E));
     HIP_TRY(h->d_wsR.reserve((size_t)grid * E));
@@ -515,11 +519,11 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
     G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p; G.wsV = h->d_wsV.p; G.wsC = h->d_wsC.p;
     G.dump_R = d_dump; G.dump_iter = dump_iter; G.dump_div = dump_div;
-    h->last_threads = 256; h->last_lds = 0; h->last_grid = grid;
+    h->last_threads = threads; h->last_lds = 0; h->last_grid = grid;
     switch (variant) {
-        case QBP_SUM_PRODUCT: hipLaunchKernelGGL(qbp::bp_generic_kernel<0>, dim3(grid), dim3(256), 0, s, G); break;
-        case QBP_DAMPED_SP:   hipLaunchKernelGGL(qbp::bp_generic_kernel<1>, dim3(grid), dim3(256), 0, s, G); break;
-        default:              hipLaunchKernelGGL(qbp::bp_generic_kernel<2>, dim3(grid), dim3(256), 0, s, G); break;
+        case QBP_SUM_PRODUCT: hipLaunchKernelGGL(qbp::bp_generic_kernel<0>, dim3(grid), dim3(threads), 0, s, G); break;
+        case QBP_DAMPED_SP:   hipLaunchKernelGGL(qbp::bp_generic_kernel<1>, dim3(grid), dim3(threads), 0, s, G); break;
+        default:              hipLaunchKernelGGL(qbp::bp_generic_kernel<2>, dim3(grid), dim3(threads), 0, s, G); break;
     }
     HIP_TRY(hipGetLastError());
     return QBP_OK;

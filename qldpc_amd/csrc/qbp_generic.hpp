@@ -1,6 +1,7 @@
 // General-H belief propagation: any parity-check matrix (irregular degrees, wide rows, large m/n:
 // space-time and circuit-level matrices).  One workgroup per
-// syndrome; messages live in a per-workgroup global-memory workspace (L2-resident for the sizes
+// syndrome (256 threads when there are enough syndromes to fill the chip, up to 1024 for the
+// one-syndrome-per-call users of large matrices); messages live in a per-workgroup global-memory workspace (L2-resident for the sizes
 // of interest) instead of registers/LDS.  Threads take checks in the check step and variables in
 // the variable step; every product / sum runs sequentially in the reference's order (ascending
 // column within a row: np.prod(axis=1); ascending check within a column: np.sum(axis=0)), so the
@@ -44,7 +45,7 @@ struct GenericParams {
 };
 
 template <int VARIANT>
-__global__ __launch_bounds__(256) void bp_generic_kernel(const GenericParams P)
+__global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int m = P.m, n = P.n, E = P.E;
