@@ -226,6 +226,11 @@ class Decoder:
                                      syn.shape[0], sol.ctypes.data))
         return sol
 
+    def osd0_device(self, d_syndromes, d_llr, d_hard, B, d_solution, stream=0):
+        """OSD-0 on device buffers (pointers as ints), enqueued on `stream`."""
+        _check(load().qbp_osd0_batch_device(self._h, d_syndromes, d_llr, d_hard, int(B), d_solution,
+                                            stream or None))
+
     def mc_sample_errors(self, p, trial_begin, T, draws=1, seed=0):
         out = np.empty((int(T), self.n), np.uint8)
         _check(load().qbp_mc_sample_errors(self._h, float(p), int(draws), int(seed),

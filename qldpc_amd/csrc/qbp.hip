@@ -419,7 +419,7 @@ try {
         while (NP < n) NP <<= 1;
         const size_t lds = (size_t)NP * 12 + (size_t)m * (W + 1) * 4 + (size_t)m * 4 + (size_t)n + 16;
         h->osd_W = W; h->osd_NP = NP; h->osd_lds = (int)((lds + 15) & ~(size_t)15);
-        h->osd_ok = lds <= 64 * 1024;
+        h->osd_ok = lds <= 64 * 1024 && m <= 64 * 32;   // (a lane tracks its rows in a 32-bit mask)
         if (h->osd_ok) {
             std::vector<uint32_t> hbits((size_t)m * W, 0u);
             for (int c = 0; c < m; ++c)
@@ -750,7 +750,15 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
     O.m = h->m; O.n = h->n; O.W = h->osd_W; O.NP = h->osd_NP; O.rank = h->osd_rank;
     O.hbits = h->d_hbits.p; O.row_ptr = h->d_row_ptr.p; O.col_idx = h->d_col_idx.p;
     const long long grid = std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 32));
-    hipLaunchKernelGGL(qbp::osd0_kernel, dim3((unsigned)grid), dim3(64), h->osd_lds, s, O);
+    // row width (32-bit words incl. the syndrome word) as a template argument for the codes of the
+    // reference: n = 72 / 90 / 108 -> 4 or 5, 144 -> 6, 288 -> 10
+    switch (h->osd_W + 1) {
+#define QBP_OSD_CASE(WW) case WW: hipLaunchKernelGGL(qbp::osd0_kernel<WW>, dim3((unsigned)grid), dim3(64), h->osd_lds, s, O); break
+        QBP_OSD_CASE(2); QBP_OSD_CASE(3); QBP_OSD_CASE(4); QBP_OSD_CASE(5); QBP_OSD_CASE(6);
+        QBP_OSD_CASE(7); QBP_OSD_CASE(8); QBP_OSD_CASE(9); QBP_OSD_CASE(10); QBP_OSD_CASE(11);
+#undef QBP_OSD_CASE
+        default: hipLaunchKernelGGL(qbp::osd0_kernel<0>, dim3((unsigned)grid), dim3(64), h->osd_lds, s, O);
+    }
     HIP_TRY(hipGetLastError());
     return QBP_OK;
 }

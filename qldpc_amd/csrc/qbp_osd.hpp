@@ -45,6 +45,8 @@ __device__ __forceinline__ bool osd_less(double ka, int ia, double kb, int ib)
 }
 
 // LDS: double keys[NP]; int idx[NP]; uint32 A[m][W+1]; int pivcol[m]; uint8 sol[n]
+// WW = W + 1 at compile time (0: any width, at most 32 rows per lane).
+template <int WW>
 __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
 {
     extern __shared__ double osd_smem[];
@@ -95,23 +97,40 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
         }
         __syncthreads();
         // ---- 3. Gauss-Jordan over the columns in reliability order            OSD.py:31-72
+        // Lane l owns rows l, l + 64, ...: per column one LDS read per owned row decides both the
+        // pivot search (ballot) and which rows take the XOR; the pivot row is read once (broadcast)
+        // into registers when it fits (WW = words per row incl. the syndrome word, compile time).
         int rank = 0;
         for (int k = 0; k < n && rank < P.rank; ++k) {   // :42-43 stops at m rows; rank(H) <= m
             const int c = idx[k];
             const int wi = c >> 5;
             const uint32_t bit = 1u << (c & 31);
             int p = -1;
-            for (int base = 0; base < m && p < 0; base += 64) {
+            unsigned has = 0;                        // bit i: row lane + 64 i has a 1 in column c
+            for (int base = 0, i = 0; base < m; base += 64, ++i) {
                 const int r = base + lane;
-                const bool cand = r < m && pivcol[r] < 0 && (A[r * RS + wi] & bit);
-                const unsigned long long mask = __ballot(cand);
-                if (mask) p = base + (int)__builtin_ctzll(mask);
+                const bool one = r < m && (A[r * RS + wi] & bit);
+                has |= (one ? 1u : 0u) << i;
+                const unsigned long long mask = __ballot(one && pivcol[r < m ? r : 0] < 0);
+                if (p < 0 && mask) p = base + (int)__builtin_ctzll(mask);
             }
             if (p < 0) continue;                     // column depends on earlier ones (:52-53)
             ++rank;
-            for (int r = lane; r < m; r += 64) {
-                if (r != p && (A[r * RS + wi] & bit)) {
-                    for (int w = 0; w <= W; ++w) A[r * RS + w] ^= A[p * RS + w];   // :63-68
+            if constexpr (WW > 0) {
+                uint32_t prow[WW];
+#pragma unroll
+                for (int w = 0; w < WW; ++w) prow[w] = A[p * RS + w];
+                for (int r = lane, i = 0; r < m; r += 64, ++i) {
+                    if (r != p && ((has >> i) & 1u)) {
+#pragma unroll
+                        for (int w = 0; w < WW; ++w) A[r * RS + w] ^= prow[w];              // :63-68
+                    }
+                }
+            } else {
+                for (int r = lane, i = 0; r < m; r += 64, ++i) {
+                    if (r != p && ((has >> i) & 1u)) {
+                        for (int w = 0; w <= W; ++w) A[r * RS + w] ^= A[p * RS + w];        // :63-68
+                    }
                 }
             }
             if (lane == 0) pivcol[p] = c;
