@@ -7,8 +7,9 @@
 // swaps or permutes: it keeps the bit-packed rows of H in LDS in their original column indexing,
 // walks the columns in sorted order, picks any not-yet-used row with a 1 in that column as the
 // pivot and XORs it into every other row that has the bit (rows are n bits + the syndrome bit).
-// Sorting: bitonic network over (|llr|, column index) pairs in LDS; ties in |llr| fall back to the
-// column index (the reference's np.argsort is unstable there; oracle/bp_oracle.c does the same).
+// Sorting: bitonic network over (|llr| as its monotone bit pattern, column index) pairs in LDS; ties
+// in |llr| fall back to the column index (the reference's np.argsort is unstable there;
+// oracle/bp_oracle.c does the same); NaN sorts last, as in numpy.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -39,7 +40,17 @@ struct OsdParams {
     long long* counters;
 };
 
-__device__ __forceinline__ bool osd_less(double ka, int ia, double kb, int ib)
+// Sort key of |llr|: the IEEE bit pattern of a non-negative double is monotone as an unsigned
+// integer (finite < inf < NaN), which is also numpy's order (np.argsort puts NaN last); every NaN
+// gets the same pattern so that NaNs, like other ties, are ordered by column index.  A total order:
+// the sorting network stays a permutation of the real columns whatever the LLRs contain.
+__device__ __forceinline__ unsigned long long osd_order_key(double llr)
+{
+    const double a = __builtin_fabs(llr);
+    return a != a ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(a);
+}
+
+__device__ __forceinline__ bool osd_less(unsigned long long ka, int ia, unsigned long long kb, int ib)
 {
     return ka < kb || (ka == kb && ia < ib);
 }
@@ -52,7 +63,7 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
     extern __shared__ double osd_smem[];
     const int lane = threadIdx.x;
     const int m = P.m, n = P.n, W = P.W, NP = P.NP, RS = P.W + 1;
-    double* keys = osd_smem;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(osd_smem);
     int* idx = reinterpret_cast<int*>(keys + NP);
     uint32_t* A = reinterpret_cast<uint32_t*>(idx + NP);
     int* pivcol = reinterpret_cast<int*>(A + (size_t)m * RS);
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
 
         // ---- 1. ordering = argsort(|llr|)                                    OSD.py:10-11
         for (int i = lane; i < NP; i += 64) {
-            keys[i] = i < n ? __builtin_fabs(llr[i]) : __builtin_inf();
+            keys[i] = i < n ? osd_order_key(llr[i]) : ~0ull;      // padding sorts behind everything
             idx[i] = i;
         }
         for (int i = lane; i < n; i += 64) sol[i] = hard[i] & 1u;
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
                     const int lo = ((t / j) * (2 * j)) + (t % j);   // element with bit j clear
                     const int hi = lo + j;
                     const bool up = (lo & k) == 0;
-                    const double ka = keys[lo], kb = keys[hi];
+                    const unsigned long long ka = keys[lo], kb = keys[hi];
                     const int ia = idx[lo], ib = idx[hi];
                     if (osd_less(kb, ib, ka, ia) == up) {
                         keys[lo] = kb; keys[hi] = ka; idx[lo] = ib; idx[hi] = ia;

@@ -6,7 +6,8 @@
   decoding/OSD.py:3            performOSD(H, syndrome, llr, hard)
   decoding/OSD_enhanced.py:5   performOSD_enhanced(..., order=0)   (must agree with performOSD)
 Inputs: (llr, hard) of reference BP runs that did not converge (performBeliefPropagationFast,
-maxIter 30, Bernoulli(0.08) errors, rng seed 20260128), plus random (llr, hard) pairs.
+maxIter 30, Bernoulli(0.08) errors, rng seed 20260128), plus random (llr, hard) pairs, plus
+random reliabilities containing +inf, -inf and NaN.
 """
 import contextlib
 import io
@@ -50,6 +51,13 @@ def main():
             syn.append((e @ H.T) % 2)
             llrs.append(rng.normal(0, 5, n)); hards.append((rng.random(n) < 0.05).astype(np.int8))
             kinds.append(1)
+        for _ in range(6):      # non-finite reliabilities: np.argsort(|llr|) puts inf, then NaN, last
+            e = (rng.random(n) < 0.1).astype(int)
+            l = rng.normal(0, 5, n)
+            pos = rng.choice(n, 3, replace=False)
+            l[pos[0]], l[pos[1]], l[pos[2]] = np.inf, -np.inf, np.nan
+            syn.append((e @ H.T) % 2); llrs.append(l)
+            hards.append((l < 0).astype(np.int8)); kinds.append(2)
         for s, l, h in zip(syn, llrs, hards):
             a = performOSD(H, s, l, h)
             b = performOSD_enhanced(H, s, l, h, order=0)

@@ -1,0 +1,227 @@
+"""GPU: randomised cross-check of every device kernel against the CPU oracle and against each other.
+
+Random matrices (shapes the on-chip kernel takes, shapes only the general-H / streaming kernels
+take, empty rows, isolated variables, wide rows and columns), random priors, variants, iteration
+limits, batch sizes and flags.  Bars:
+
+* the device kernels (automatic choice, general-H, streaming) return identical bits on EVERY input;
+* device == oracle in hard decision, converged flag and iteration on every syndrome the oracle
+  decodes within 15 iterations (and on all of them when the iteration limit is <= 7), except
+  syndromes whose trajectory the replay below flags as noise-driven (an exact cancellation whose
+  rounding residue decides a bit, or which the reference scales up by dividing by +1e-15,
+  beliefPropagation.py:122-123: there two tanh/arctanh implementations legitimately part ways,
+  DESIGN.md section 2);
+* OSD-0 and the Monte-Carlo counters: identical to the oracle pipeline.
+
+The default run is short (part of ``pytest -m gpu``); ``QBP_FUZZ_CASES=2000 python -m pytest
+tests/test_gpu_fuzz.py -s`` is the long campaign (profiles/r01_fuzz.txt holds one).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from qldpc_amd import _lib, bp
+
+pytestmark = pytest.mark.gpu
+
+CASES = int(os.environ.get("QBP_FUZZ_CASES", "60"))
+
+
+def capped_matrix(rng, m, n, max_row, max_col, fill):
+    """Random H with row weights <= max_row and column weights <= max_col."""
+    H = np.zeros((m, n), np.int64)
+    colw = np.zeros(n, np.int64)
+    for c in range(m):
+        want = int(rng.integers(0 if rng.random() < 0.03 else 1, max_row + 1))
+        free = np.flatnonzero(colw < max_col)
+        if len(free) == 0 or want == 0:
+            continue
+        pick = rng.choice(free, min(want, len(free)), replace=False)
+        if rng.random() < fill:
+            H[c, pick] = 1
+            colw[pick] += 1
+        else:
+            H[c, pick[:max(1, len(pick) // 2)]] = 1
+            colw[pick[:max(1, len(pick) // 2)]] += 1
+    return H
+
+
+def random_matrix(rng):
+    kind = rng.choice(["cap63", "cap63", "cap84", "wide", "tiny"])
+    if kind == "cap63":
+        m = int(rng.integers(2, 260)); n = int(rng.integers(max(2, m // 2), 2 * m + 8))
+        return kind, capped_matrix(rng, m, n, 6, 3, rng.uniform(0.5, 1.0))
+    if kind == "cap84":
+        m = int(rng.integers(2, 200)); n = int(rng.integers(max(2, m // 2), 3 * m + 8))
+        return kind, capped_matrix(rng, m, n, 8, 4, rng.uniform(0.5, 1.0))
+    if kind == "wide":
+        m = int(rng.integers(1, 60)); n = int(rng.integers(2, 120))
+        return kind, (rng.random((m, n)) < rng.uniform(0.03, 0.3)).astype(np.int64)
+    m = int(rng.integers(1, 6)); n = int(rng.integers(1, 10))
+    return kind, (rng.random((m, n)) < 0.5).astype(np.int64)
+
+
+def noise_driven(H, syn, prior, max_iter, variant, alpha, damping, clip_llr):
+    """Replay of the sum-product trajectories: True where the outcome hangs on rounding residue --
+    (a) some message Q = value - R is an exact cancellation (|Q| < 1e-12 |R|): whether its tanh falls
+    below the reference's 1e-15 threshold, and is then scaled by 1e15, differs between implementations, or (b) some posterior value is an exact cancellation of
+    macroscopic terms (|value| < 1e-12 of their magnitude, e.g. a weight-2 check returning
+    2 atanh(tanh(prior / 2)) = -prior to a weight-1 variable with the same prior): its sign, i.e. the
+    hard-decision bit and the convergence test, is then last-ulp noise of tanh/arctanh."""
+    flags = np.zeros(len(syn), bool)
+    if variant == _lib.MIN_SUM:
+        return flags
+    rows, cols = np.nonzero(H)
+    if len(rows) == 0:
+        return flags
+    with np.errstate(all="ignore"):
+        for i, s in enumerate(syn):
+            sign = 1.0 - 2.0 * s[rows]
+            Q = prior[cols].astype(float)
+            R = np.zeros(len(rows))
+            for _ in range(max_iter):
+                # (a): Q = value - R cancelled to residue (exactly 0 here may be 1e-15 elsewhere)
+                if ((np.abs(Q) < 1e-12 * np.abs(R)) & (np.abs(R) > 1e-9)).any():
+                    flags[i] = True
+                    break
+                t = np.tanh(Q / 2)
+                prod = np.ones(H.shape[0])
+                np.multiply.at(prod, rows, t)
+                ts = np.where(np.abs(t) < 1e-15, 1e-15, t)
+                R = 2 * np.arctanh(np.clip(prod[rows] / ts * sign, -0.9999999, 0.9999999))
+                if variant == _lib.DAMPED_SP:
+                    R = R * alpha
+                tot = np.zeros(H.shape[1])
+                np.add.at(tot, cols, R)
+                val = tot + prior
+                mag = np.zeros(H.shape[1])
+                np.add.at(mag, cols, np.abs(R))
+                if ((np.abs(val) < 1e-12 * (mag + np.abs(prior))) & (val != 0) & (mag > 1e-9)).any():
+                    flags[i] = True
+                    break
+                Qn = val[cols] - R
+                Q = Qn if variant == _lib.SUM_PRODUCT else np.clip(damping * Qn + (1 - damping) * Q,
+                                                                   -clip_llr, clip_llr)
+                if np.array_equal(((val < 0).astype(np.int64) @ H.T) % 2, s):
+                    break
+    return flags
+
+
+def test_fuzz_decode_kernels_vs_oracle():
+    rng = np.random.default_rng(int(os.environ.get("QBP_FUZZ_SEED", "20261004")))
+    stats = dict(cases=0, syndromes=0, noisy=0, chaotic=0, kinds={}, kernels={1: 0, 2: 0, 3: 0})
+    for case in range(CASES):
+        kind, H = random_matrix(rng)
+        m, n = H.shape
+        B = int(rng.choice([1, 3, 17, 64, 200, 600]))
+        if rng.random() < 0.5:
+            pv = np.full(n, rng.uniform(0.005, 0.2))
+        else:
+            pv = rng.uniform(0.005, 0.3, n)
+        prior = np.log((1 - pv) / pv)
+        err = (rng.random((B, n)) < pv * rng.uniform(0.3, 1.5)).astype(np.int64)
+        syn = (err @ H.T % 2).astype(np.uint8)
+        if rng.random() < 0.2:
+            syn[rng.integers(0, B)] = rng.random(m) < 0.5          # a syndrome outside the model
+        variant = int(rng.choice([_lib.SUM_PRODUCT, _lib.SUM_PRODUCT, _lib.DAMPED_SP, _lib.MIN_SUM]))
+        kw = dict(alpha=1.0, damping=1.0, clip_llr=20.0)
+        if variant != _lib.SUM_PRODUCT:
+            kw = dict(alpha=float(rng.uniform(0.6, 1.0)), damping=float(rng.uniform(0.5, 1.0)),
+                      clip_llr=float(rng.uniform(10, 30)))
+        max_iter = int(rng.choice([1, 2, 7, 25, 50]))
+        flags = _lib.FLAG_FORCE_FULL if rng.random() < 0.3 else 0
+        tag = f"case {case} {kind} {m}x{n} B={B} variant={variant} it={max_iter} flags={flags} {kw}"
+
+        dec = bp.decoder_for(H)
+        outs = {}
+        for k in (_lib.KERNEL_AUTO, _lib.KERNEL_GENERAL, _lib.KERNEL_STREAM):
+            dec.set_option(_lib.OPT_KERNEL, k)
+            try:
+                outs[k] = dec.decode(syn, prior, max_iter, variant, flags=flags, **kw)
+                stats["kernels"][dec.info("last_kernel")] += 1
+            finally:
+                dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
+        a = outs[_lib.KERNEL_AUTO]
+        for k in (_lib.KERNEL_GENERAL, _lib.KERNEL_STREAM):
+            for x, y in zip(a, outs[k]):
+                assert np.array_equal(x, y, equal_nan=True), f"kernel {k} differs from the default: {tag}"
+
+        o = oracle.decode_batch(H, syn, prior, max_iter, variant, threads=8, **kw)
+        same = (a[0] == o[0]).all(axis=1) & (a[1] == o[1]) & (a[2] == o[2])
+        # Compared strictly: syndromes the oracle decodes within 15 iterations, and everything when
+        # the iteration limit is small.  Trajectories that run long without converging amplify
+        # last-ulp differences chaotically; they are only counted.
+        strict = (o[1] & (o[2] <= 15)) | (max_iter <= 7)
+        if not same[strict].all():
+            noisy = noise_driven(H, syn, prior, max_iter, variant, **kw)
+            bad = ~same & ~noisy & strict
+            assert not bad.any(), f"{int(bad.sum())} syndromes differ from the oracle: {tag}"
+            stats["noisy"] += int((~same & strict).sum())
+        stats["chaotic"] += int((~same & ~strict).sum())
+        quick = same & a[1] & (a[2] <= 10)
+        fin = np.isfinite(o[3]) & quick[:, None]
+        err_abs = np.abs(np.where(fin, a[3], 0.0) - np.where(fin, o[3], 0.0))
+        tol = np.maximum(1e-5 * np.abs(np.where(fin, o[3], 0.0)), 1e-7)
+        if not (err_abs <= tol).all():
+            noisy = noise_driven(H, syn, prior, max_iter, variant, **kw)
+            assert (err_abs <= tol)[~noisy].all(), f"LLR error {err_abs.max():.3e}: {tag}"
+        stats["cases"] += 1
+        stats["syndromes"] += B
+        stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
+    print(f"fuzz decode: {stats}")
+
+
+def test_fuzz_osd_vs_oracle():
+    rng = np.random.default_rng(77)
+    done = 0
+    for case in range(max(CASES // 4, 8)):
+        kind, H = random_matrix(rng)
+        m, n = H.shape
+        dec = bp.decoder_for(H)
+        B = int(rng.choice([1, 5, 40]))
+        llr = rng.normal(0, 5, (B, n))
+        if rng.random() < 0.5:
+            llr = np.round(llr)                                   # many ties in |llr|
+        hard = (llr < 0).astype(np.uint8)
+        err = (rng.random((B, n)) < 0.1).astype(np.int64)
+        syn = (err @ H.T % 2).astype(np.uint8)                    # always in the column space
+        sol = dec.osd0(syn, llr, hard)
+        for i in range(B):
+            ref = oracle.osd0(H, syn[i], llr[i], hard[i])
+            assert np.array_equal(sol[i], ref), f"OSD-0 differs: case {case} {kind} {m}x{n}"
+            assert np.array_equal(sol[i].astype(np.int64) @ H.T % 2, syn[i])
+        done += B
+    print(f"fuzz OSD-0: {done} solutions identical to the oracle")
+
+
+def test_fuzz_mc_counters_vs_oracle():
+    rng = np.random.default_rng(99)
+    done = 0
+    for case in range(max(CASES // 6, 6)):
+        m = int(rng.integers(8, 120)); n = int(rng.integers(m, 2 * m + 4))
+        H = capped_matrix(rng, m, n, 6, 3, 1.0)
+        k = int(rng.integers(1, 9))
+        Lx = (rng.random((k, n)) < 0.3).astype(np.uint8)
+        p = float(rng.uniform(0.01, 0.08))
+        prior = np.full(n, np.log((1 - p) / p))
+        T = int(rng.integers(200, 3000)); t0 = int(rng.integers(0, 10**9))
+        draws = int(rng.integers(1, 3)); seed = int(rng.integers(0, 2**40))
+        distance = int(rng.integers(2, 12))
+        variant = int(rng.choice([_lib.SUM_PRODUCT, _lib.MIN_SUM]))
+        kw = dict(alpha=0.8, damping=0.7, clip_llr=25.0) if variant == _lib.MIN_SUM else {}
+        osd = bool(rng.random() < 0.5)
+        dec = bp.decoder_for(H)
+        got = dec.mc_run(Lx, distance, p, prior, t0, t0 + T, draws=draws, seed=seed, max_iter=30,
+                         variant=variant, flags=_lib.FLAG_OSD0 if osd else 0, **kw)
+        ref = oracle.mc_counters(H, Lx, distance, p, prior, t0, t0 + T, draws=draws, seed=seed,
+                                 max_iter=30, variant=variant, osd=osd, **kw)
+        if not np.array_equal(np.asarray(got)[:len(ref)], np.asarray(ref)):
+            errors = oracle.mc_errors(n, p, draws, seed, t0, T)
+            syn = (errors.astype(np.int64) @ H.T % 2).astype(np.uint8)
+            noisy = noise_driven(H, syn, prior, 30, variant, kw.get("alpha", 1.0), kw.get("damping", 1.0),
+                                 kw.get("clip_llr", 20.0))
+            assert noisy.any(), f"MC counters differ: case {case} {m}x{n} T={T} osd={osd} {got} vs {ref}"
+        done += T
+    print(f"fuzz Monte-Carlo: {done} trials, counters identical to the oracle pipeline")
