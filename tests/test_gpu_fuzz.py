@@ -98,7 +98,7 @@ def noise_driven(H, syn, prior, max_iter, variant, alpha, damping, clip_llr):
                 val = tot + prior
                 mag = np.zeros(H.shape[1])
                 np.add.at(mag, cols, np.abs(R))
-                if ((np.abs(val) < 1e-12 * (mag + np.abs(prior))) & (val != 0) & (mag > 1e-9)).any():
+                if ((np.abs(val) < 1e-12 * (mag + np.abs(prior))) & (mag > 1e-9)).any():   # (exactly 0 here may be +-1e-15 elsewhere)
                     flags[i] = True
                     break
                 Qn = val[cols] - R
