@@ -170,6 +170,8 @@ def test_fuzz_decode_kernels_vs_oracle():
         stats["cases"] += 1
         stats["syndromes"] += B
         stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
+        if (case + 1) % 500 == 0:
+            print(f"  ... {case + 1} cases, {stats['syndromes']} syndromes", flush=True)
     print(f"fuzz decode: {stats}")
 
 
