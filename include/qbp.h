@@ -82,7 +82,8 @@ int qbp_plan(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t 
 
 /*
  * Decode B syndromes (host buffers).
- *   syndromes [B][m] 0/1 bytes, prior [n] LLRs (initialBelief), max_iter >= 1,
+ *   syndromes [B][m] 0/1 bytes, prior [n] LLRs (initialBelief; +-inf allowed, NaN rejected with
+ *   QBP_E_INVALID -- the _device entry points cannot check and clip NaN messages away), max_iter >= 1,
  *   variant QBP_*, alpha / damping / clip_llr as in rework/decoding.py (ignored by
  *   QBP_SUM_PRODUCT; alpha is R-scaling for QBP_DAMPED_SP and the normalisation for QBP_MIN_SUM).
  * Outputs (any may be NULL): hard [B][n] 0/1, converged [B] 0/1, iters [B] (0-based iteration of

@@ -10,7 +10,8 @@ Same names, positional order, defaults, return arity, dtypes and printed lines a
 All decoding runs on the MI355X; there is no CPU path in this package.  Deviations from the
 reference, all on inputs the reference does not handle either:
 ``maxIter < 1`` raises ``ValueError`` (reference: ``UnboundLocalError``), shape mismatches raise
-``ValueError`` (reference: numpy ``IndexError``/broadcast errors), syndrome entries must be 0/1.
+``ValueError`` (reference: numpy ``IndexError``/broadcast errors), syndrome entries must be 0/1,
+priors must not be NaN (+-inf are fine).
 """
 from __future__ import annotations
 
@@ -102,6 +103,10 @@ def _prior(initialBelief, n):
     p = np.asarray(initialBelief, dtype=np.float64)
     if p.shape != (n,):
         raise ValueError(f"initialBelief has shape {p.shape}, expected ({n},)")
+    if np.isnan(p).any():
+        # (+-inf are legal: p = 0 or 1.  The reference turns a NaN prior into NaN messages on the
+        # whole connected component; the device kernels clip with min/max, which drop NaNs.)
+        raise ValueError("initialBelief contains NaN")
     return p
 
 

@@ -622,6 +622,8 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
     if (rc) return rc;
     if (B == 0) return QBP_OK;
     if (!syndromes || !prior) return fail(QBP_E_INVALID, "null input pointer");
+    for (int v = 0; v < h->n; ++v)
+        if (prior[v] != prior[v]) return fail(QBP_E_INVALID, "prior[%d] is NaN (+-inf are legal)", v);
     HIP_TRY(hipSetDevice(h->device));
     const size_t m = h->m, n = h->n, b = (size_t)B;
     {

@@ -199,3 +199,11 @@ def test_host_tables_of_the_on_chip_kernel(lib):
     assert _plan(lib, big)[0][0] == 1
     big = np.kron(np.eye(16, dtype=np.int64), c144)                                  # m = 1152
     assert _plan(lib, csr_matrix(big))[0][0] == 2
+
+
+def test_nan_prior_rejected_by_the_shim():
+    """NaN priors are an input error here (bp._prior); +-inf (p = 0 or 1) stay legal."""
+    from qldpc_amd import bp
+    with pytest.raises(ValueError, match="NaN"):
+        bp._prior([0.5, float("nan"), 1.0], 3)
+    assert np.isinf(bp._prior([np.inf, -np.inf, 1.0], 3)[:2]).all()
