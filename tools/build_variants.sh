@@ -1,6 +1,8 @@
 #!/bin/bash
-# Build experiment variants of the streaming kernel (compile-time switches of qbp_stream.hpp) into
-# build/variants/ (git-ignored, travels with gpurun).  Usage: tools/stream_variants.sh name:flags ...
+# Build experiment variants of libqbp.so (extra -D / compiler flags) into build/variants/ (git-ignored,
+# travels with gpurun); tools/ab_run.py then runs one benchmark script per variant on the same box:
+#   tools/build_variants.sh "base:" "vu8:-DQBP_STREAM_VU=8"
+#   gpurun -- 'python tools/ab_run.py tools/bench_stream.py'
 set -eu
 cd "$(dirname "$0")/.."
 mkdir -p build/variants
