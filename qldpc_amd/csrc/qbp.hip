@@ -108,6 +108,8 @@ struct qbp_handle {
     int opt_kernel = 0;             // 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome), 3 streaming
     DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes
     DevBuf<int32_t> d_srow, d_srow_e0, d_srow_deg, d_svar, d_sedge;   // weight-class tables
+    DevBuf<int32_t> d_epos, d_cpos;
+    int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
     // pinned, device-mapped staging for small host-pointer calls (zero-copy: no hipMemcpy at all)
@@ -198,6 +200,9 @@ struct HostTables {
     std::vector<int32_t> iso, col_ptr, col_edge;
     // streaming kernel: checks / variables sorted by weight class (qbp_stream.hpp)
     std::vector<int32_t> srow, srow_e0, srow_deg, svar, sedge;
+    // general-H kernel: class-blocked transposed message layout (qbp_generic.hpp)
+    std::vector<int32_t> epos, cpos;
+    int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
 };
@@ -268,6 +273,23 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
         }
     }
     T.row_off[RC + 2] = m;
+    static_assert(qbp::GENERIC_MAX_ROW_CLASS == qbp::STREAM_MAX_ROW_CLASS, "shared row classes");
+    T.epos.assign((size_t)std::max(E, 1), 0);
+    T.cpos.assign((size_t)std::max(E, 1), 0);
+    {
+        int base = 0;
+        for (int k = 1; k <= RC; ++k) {                 // block of the weight-k checks: [entry j][check i]
+            const int cnt = T.row_off[k + 1] - T.row_off[k];
+            T.row_base[k] = base;
+            for (int i = 0; i < cnt; ++i)
+                for (int j = 0; j < k; ++j) T.epos[T.srow_e0[T.row_off[k] + i] + j] = base + j * cnt + i;
+            base += k * cnt;
+        }
+        T.row_base[RC + 1] = base;                      // longer checks: entries contiguous
+        for (int i = T.row_off[RC + 1]; i < T.row_off[RC + 2]; ++i)
+            for (int j = 0; j < T.srow_deg[i]; ++j) T.epos[T.srow_e0[i] + j] = base++;
+    }
+    for (int q = 0; q < E; ++q) T.cpos[q] = T.epos[T.col_edge[q]];
     for (int k = 0; k <= CC + 1; ++k) {
         T.col_off[k] = (int)T.svar.size();
         T.col_edge_base[k] = (int)T.sedge.size();
@@ -403,6 +425,9 @@ try {
     up(h->d_iso, T.iso);
     up(h->d_col_ptr, T.col_ptr);
     up(h->d_col_edge, T.col_edge);
+    up(h->d_epos, T.epos);
+    up(h->d_cpos, T.cpos);
+    std::copy(std::begin(T.row_base), std::end(T.row_base), h->row_base);
     up(h->d_srow, T.srow);
     up(h->d_srow_e0, T.srow_e0);
     up(h->d_srow_deg, T.srow_deg);
@@ -488,6 +513,7 @@ void qbp_destroy(qbp_handle* h)
     h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
     h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release(); h->d_svar.release(); h->d_sedge.release();
     h->d_srow.release(); h->d_srow_e0.release(); h->d_srow_deg.release();
+    h->d_epos.release(); h->d_cpos.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
@@ -512,8 +538,11 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     HIP_TRY(h->d_wsC.reserve((size_t)grid * n));
     qbp::GenericParams G{};
     G.m = h->m; G.n = h->n; G.E = h->E;
-    G.row_ptr = h->d_row_ptr.p; G.col_idx = h->d_col_idx.p;
-    G.col_ptr = h->d_col_ptr.p; G.col_edge = h->d_col_edge.p;
+    G.col_idx = h->d_col_idx.p; G.col_ptr = h->d_col_ptr.p;
+    G.srow = h->d_srow.p; G.srow_e0 = h->d_srow_e0.p; G.srow_deg = h->d_srow_deg.p;
+    G.epos = h->d_epos.p; G.cpos = h->d_cpos.p;
+    std::copy(std::begin(h->row_off), std::end(h->row_off), G.row_off);
+    std::copy(std::begin(h->row_base), std::end(h->row_base), G.row_base);
     G.syndromes = d_syndromes; G.prior = d_prior; G.B = B; G.max_iter = max_iter; G.flags = flags;
     G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
     G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
@@ -586,12 +615,15 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     if (B > (int64_t)1 << 40) return fail(QBP_E_INVALID, "B too large");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // kernel choice: the on-chip kernel when the matrix fits; otherwise one lane per syndrome
-    // (streaming) for batches large enough to fill the chip, one workgroup per syndrome below that
+    // kernel choice: the on-chip kernel when the matrix fits; otherwise one workgroup per syndrome
+    // (general-H), except for small graphs in batches that fill the chip with one LANE per syndrome,
+    // where the streaming kernel is ahead (tools/bench_generic.py: [[288,12,18]], 262144 syndromes:
+    // 3.7e6 against 2.6e6 /s; larger graphs keep their messages in L2 / Infinity Cache under the
+    // general-H kernel and win there at every batch size measured)
     int kernel = h->opt_kernel;
     if (h->opt_force_generic) kernel = 2;
     if (kernel == 1 && !h->fused_ok) return fail(QBP_E_UNSUPPORTED, "H does not fit the on-chip kernel");
-    if (kernel == 0) kernel = h->fused_ok ? 1 : (B >= 16384 ? 3 : 2);
+    if (kernel == 0) kernel = h->fused_ok ? 1 : ((B >= 131072 && h->E <= 2048) ? 3 : 2);
     h->last_kernel = kernel;
     if (kernel == 3)
         return stream_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr, flags,
@@ -957,7 +989,7 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
         case QBP_INFO_KERNEL_KIND:   // the kernel a decode call would use (small batch), see also ..._LAST
             if (h->opt_force_generic) return 2;
             if (h->opt_kernel) return h->opt_kernel;
-            return h->fused_ok ? 1 : 2;   // (auto picks 3 for batches >= 16384 when not on-chip)
+            return h->fused_ok ? 1 : 2;   // (auto picks 3 for small graphs in batches >= 131072)
         case QBP_INFO_LAST_KERNEL: return h->last_kernel;
         case QBP_INFO_THREADS: return h->last_threads;
         case QBP_INFO_LDS_BYTES: return h->last_lds;

@@ -1,10 +1,10 @@
 // General-H belief propagation: any parity-check matrix (irregular degrees, wide rows, large m/n:
 // space-time and circuit-level matrices).  One workgroup per
 // syndrome (256 threads when there are enough syndromes to fill the chip, up to 1024 for the
-// one-syndrome-per-call users of large matrices); messages live in a per-workgroup global-memory workspace (L2-resident for the sizes
-// of interest) instead of registers/LDS.  Threads take checks in the check step and variables in
-// the variable step; every product / sum runs sequentially in the reference's order (ascending
-// column within a row: np.prod(axis=1); ascending check within a column: np.sum(axis=0)), so the
+// one-syndrome-per-call users of large matrices); messages live in a per-workgroup global-memory
+// workspace (L2-resident for the sizes of interest) instead of registers/LDS.  Threads take checks
+// in the check step (by weight class: coalesced, straight-line) and variables in the variable step;
+// every product / sum runs sequentially in the reference's order (ascending column within a row: np.prod(axis=1); ascending check within a column: np.sum(axis=0)), so the
 // arithmetic is the same as the fused kernel's and the oracle's.
 #pragma once
 
@@ -15,12 +15,23 @@
 
 namespace qbp {
 
+constexpr int GENERIC_MAX_ROW_CLASS = 8;   // rows of weight 1 .. 8 have their own instantiation
+
 struct GenericParams {
     int m, n, E;
-    const int32_t* row_ptr;     // CSR
-    const int32_t* col_idx;
-    const int32_t* col_ptr;     // CSC: edge ids of each column in ascending check order
-    const int32_t* col_edge;
+    const int32_t* col_idx;     // CSR column indices
+    const int32_t* col_ptr;     // CSC
+    // Message layout of one syndrome ("class-blocked, transposed"): checks are sorted by row weight
+    // (stable; build_tables in qbp.hip); the cnt checks of weight D occupy one block in which entry
+    // j of the i-th such check sits at row_base[D] + j * cnt + i, so that consecutive threads (one
+    // check each) touch consecutive doubles.  Checks of weight > 8 keep their entries contiguous.
+    const int32_t* srow;        // [m] check index, sorted by weight class
+    const int32_t* srow_e0;     // [m] first CSR edge of that check
+    const int32_t* srow_deg;    // [m] its weight
+    const int32_t* epos;        // [E] CSR edge -> position in the layout
+    const int32_t* cpos;        // [E] CSC slot (column-major, ascending check) -> position
+    int row_off[GENERIC_MAX_ROW_CLASS + 3];    // class boundaries in srow (0 .. 8, > 8)
+    int row_base[GENERIC_MAX_ROW_CLASS + 2];   // first position of each class block
     const uint8_t* syndromes;
     const double* prior;
     long long B;
@@ -44,11 +55,66 @@ struct GenericParams {
     double dump_div;
 };
 
+// Check update of one row held in registers: q[D] -> r[D]   (beliefPropagation.py:114-126 /
+// rework/decoding.py:28-56).  `scale` is false for the alpha_estimation dump of the damped variant
+// (rework/decoding.py:168-169 returns R before the alpha scaling).
+template <int VARIANT, int D>
+__device__ __forceinline__ void generic_row_update(const double (&q)[D], double (&r)[D], unsigned sbit,
+                                                   double alpha, bool scale)
+{
+    if constexpr (VARIANT == 2) {
+        double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
+        int min1_j = -1;
+        bool anynan = false;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            sprod *= q[j] < 0.0 ? -1.0 : 1.0;
+            anynan |= q[j] != q[j];
+            const double a = __builtin_fabs(q[j]);
+            if (a < min1) { min1 = a; min1_j = j; }
+        }
+        // np.sign(nan) = nan: one NaN message makes the row's sign product, hence every R of the
+        // row, NaN (rework/decoding.py:28-35; inf - inf with infinite priors)
+        if (anynan) sprod = __builtin_nan("");
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double a = __builtin_fabs(q[j]);
+            if (j != min1_j && a < min2) min2 = a;
+        }
+        const double as = sbit ? -alpha : alpha;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double sg = q[j] < 0.0 ? -1.0 : 1.0;
+            const double mag = (__builtin_fabs(q[j]) == min1) ? min2 : min1;
+            r[j] = (as * (sprod * sg)) * mag;
+        }
+    } else {
+        double t[D];
+        double prod = 1.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            t[j] = tanh_half(q[j]);
+            prod = (j == 0) ? t[0] : prod * t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+            double po = div_nr(prod, ts);
+            po = sbit ? -po : po;
+            const double x = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+            r[j] = (VARIANT == 1 && scale) ? x * alpha : x;
+        }
+    }
+}
+
+// __launch_bounds__(1024) = at most 128 registers: also right for the 256-thread launches, which
+// then fit 4 workgroups per CU (a 135-register build with 3 per CU was 30 % slower).
 template <int VARIANT>
 __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int m = P.m, n = P.n, E = P.E;
+    constexpr int RC = GENERIC_MAX_ROW_CLASS;
     double* Q = P.wsQ + (size_t)blockIdx.x * E;
     double* R = P.wsR + (size_t)blockIdx.x * E;
     double* V = P.wsV + (size_t)blockIdx.x * n;
@@ -58,93 +124,110 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 
     for (long long b = blockIdx.x; b < P.B; b += gridDim.x) {
         const uint8_t* syn = P.syndromes + b * m;
-        for (int e = tid; e < E; e += nt) Q[e] = P.prior[P.col_idx[e]];
+        for (int e = tid; e < E; e += nt) Q[P.epos[e]] = P.prior[P.col_idx[e]];   // Q = prior on edges
         __syncthreads();
         bool frozen = false;
         int it = 0;
         for (; it < P.max_iter; ++it) {
-            // ---- check step (beliefPropagation.py:114-126 / rework/decoding.py:28-56) ----------
-            for (int c = tid; c < m; c += nt) {
-                const int b0 = P.row_ptr[c], e1 = P.row_ptr[c + 1];
-                const unsigned sbit = syn[c] & 1u;
+            const bool scale = !(P.dump_R != nullptr && it == P.dump_iter);
+            // ---- check step, one thread per check, by weight class: D coalesced loads, straight-
+            //      line arithmetic, D coalesced stores
+#define QBP_ROW_CLASS(D)                                                                          \
+            {                                                                                     \
+                const int cnt = P.row_off[D + 1] - P.row_off[D];                                  \
+                for (int i = tid; i < cnt; i += nt) {                                             \
+                    const unsigned sbit = syn[P.srow[P.row_off[D] + i]] & 1u;                      \
+                    double q[D], r[D];                                                            \
+                    _Pragma("unroll") for (int j = 0; j < D; ++j) q[j] = Q[P.row_base[D] + j * cnt + i]; \
+                    generic_row_update<VARIANT, D>(q, r, sbit, P.alpha, scale);                   \
+                    _Pragma("unroll") for (int j = 0; j < D; ++j) R[P.row_base[D] + j * cnt + i] = r[j]; \
+                }                                                                                 \
+            }
+            QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
+            QBP_ROW_CLASS(5) QBP_ROW_CLASS(6) QBP_ROW_CLASS(7) QBP_ROW_CLASS(8)
+#undef QBP_ROW_CLASS
+            for (int i = P.row_off[RC + 1] + tid; i < P.row_off[RC + 2]; i += nt) {   // weight > 8
+                const int deg = P.srow_deg[i];
+                const int p0 = P.epos[P.srow_e0[i]];            // entries contiguous from here
+                const unsigned sbit = syn[P.srow[i]] & 1u;
                 if constexpr (VARIANT == 2) {
                     double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
-                    int min1_e = -1;
+                    int min1_j = -1;
                     bool anynan = false;
-                    for (int e = b0; e < e1; ++e) {
-                        const double q = Q[e];
-                        sprod *= q < 0.0 ? -1.0 : 1.0;
-                        anynan |= q != q;
-                        const double a = __builtin_fabs(q);
-                        if (a < min1) { min1 = a; min1_e = e; }
+                    for (int j = 0; j < deg; ++j) {
+                        const double x = Q[p0 + j];
+                        sprod *= x < 0.0 ? -1.0 : 1.0;
+                        anynan |= x != x;
+                        const double a = __builtin_fabs(x);
+                        if (a < min1) { min1 = a; min1_j = j; }
                     }
-                    // np.sign(nan) = nan: one NaN message makes the row's sign product, hence every
-                    // R of the row, NaN (rework/decoding.py:28-35; inf - inf with infinite priors)
                     if (anynan) sprod = __builtin_nan("");
-                    for (int e = b0; e < e1; ++e) {
-                        const double a = __builtin_fabs(Q[e]);
-                        if (e != min1_e && a < min2) min2 = a;
+                    for (int j = 0; j < deg; ++j) {
+                        const double a = __builtin_fabs(Q[p0 + j]);
+                        if (j != min1_j && a < min2) min2 = a;
                     }
                     const double as = sbit ? -P.alpha : P.alpha;
-                    for (int e = b0; e < e1; ++e) {
-                        const double q = Q[e];
-                        const double s = q < 0.0 ? -1.0 : 1.0;
-                        const double mag = (__builtin_fabs(q) == min1) ? min2 : min1;
-                        R[e] = (as * (sprod * s)) * mag;
+                    for (int j = 0; j < deg; ++j) {
+                        const double x = Q[p0 + j];
+                        const double sg = x < 0.0 ? -1.0 : 1.0;
+                        const double mag = (__builtin_fabs(x) == min1) ? min2 : min1;
+                        R[p0 + j] = (as * (sprod * sg)) * mag;
                     }
                 } else {
                     double prod = 1.0;
-                    for (int e = b0; e < e1; ++e) {
-                        const double t = tanh_half(Q[e]);
-                        R[e] = t;                                  // R holds tanh for now
-                        prod = (e == b0) ? t : prod * t;
+                    for (int j = 0; j < deg; ++j) {
+                        const double t = tanh_half(Q[p0 + j]);
+                        R[p0 + j] = t;                             // R holds tanh for now
+                        prod = (j == 0) ? t : prod * t;
                     }
-                    for (int e = b0; e < e1; ++e) {
-                        const double t = R[e];
+                    for (int j = 0; j < deg; ++j) {
+                        const double t = R[p0 + j];
                         const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
                         double po = div_nr(prod, ts);
                         po = sbit ? -po : po;
-                        const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
-                        // the alpha_estimation dump (rework/decoding.py:168-169) precedes the scaling
-                        R[e] = (VARIANT == 1 && !(P.dump_R != nullptr && it == P.dump_iter)) ? r * P.alpha : r;
+                        const double x = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+                        R[p0 + j] = (VARIANT == 1 && scale) ? x * P.alpha : x;
                     }
                 }
             }
             __syncthreads();
-            if (P.dump_R != nullptr && it == P.dump_iter) {
-                for (int e = tid; e < E; e += nt) P.dump_R[b * E + e] = R[e] / P.dump_div;
+            if (!scale) {
+                for (int e = tid; e < E; e += nt) P.dump_R[b * E + e] = R[P.epos[e]] / P.dump_div;
                 frozen = true;           // nothing else is reported for this syndrome
                 break;
             }
-            // ---- variable step (:129-136) ------------------------------------------------------
+            // ---- variable step (:129-136), one thread per variable: value, candidate error and
+            //      the new variable->check messages of its column
             for (int v = tid; v < n; v += nt) {
                 double s = 0.0;
                 const int k0 = P.col_ptr[v], k1 = P.col_ptr[v + 1];
                 for (int k = k0; k < k1; ++k) {
-                    const double r = R[P.col_edge[k]];
-                    s = (k == k0) ? r : s + r;
+                    const double r = R[P.cpos[k]];
+                    s = (k == k0) ? r : s + r;                      // ascending check order
                 }
                 const double val = s + P.prior[v];
                 V[v] = val;
                 cand[v] = val < 0.0;
-            }
-            __syncthreads();
-            for (int e = tid; e < E; e += nt) {
-                const double qn = V[P.col_idx[e]] - R[e];
-                if constexpr (VARIANT == 0) {
-                    Q[e] = qn;
-                } else {
-                    const double q = P.damping * qn + one_minus_damping * Q[e];
-                    const double y = q < -P.clip_llr ? -P.clip_llr : q;     // np.clip, NaN stays NaN
-                    Q[e] = y > P.clip_llr ? P.clip_llr : y;
+                for (int k = k0; k < k1; ++k) {
+                    const int o = P.cpos[k];
+                    const double qn = val - R[o];
+                    if constexpr (VARIANT == 0) {
+                        Q[o] = qn;
+                    } else {
+                        const double q = P.damping * qn + one_minus_damping * Q[o];
+                        const double y = q < -P.clip_llr ? -P.clip_llr : q;     // np.clip, NaN stays NaN
+                        Q[o] = y > P.clip_llr ? P.clip_llr : y;
+                    }
                 }
             }
+            __syncthreads();
             // ---- syndrome check (:137-139) -----------------------------------------------------
             int unsat = 0;
             if (!frozen) {
-                for (int c = tid; c < m; c += nt) {
-                    unsigned par = syn[c] & 1u;
-                    for (int e = P.row_ptr[c]; e < P.row_ptr[c + 1]; ++e) par ^= cand[P.col_idx[e]];
+                for (int i = tid; i < m; i += nt) {
+                    unsigned par = syn[P.srow[i]] & 1u;
+                    const int e0 = P.srow_e0[i], deg = P.srow_deg[i];
+                    for (int j = 0; j < deg; ++j) par ^= cand[P.col_idx[e0 + j]];
                     unsat |= (int)par;
                 }
             }

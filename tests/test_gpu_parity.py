@@ -319,8 +319,8 @@ def test_handle_lifecycle_and_input_types():
 
 
 def test_auto_kernel_choice_for_wide_matrices():
-    """A matrix too wide for the on-chip kernel: small batches go to the general-H kernel
-    (workgroup per syndrome), batches of >= 16384 syndromes to the streaming kernel; same bits."""
+    """A matrix too wide for the on-chip kernel goes to the general-H kernel (workgroup per
+    syndrome); batches of >= 131072 syndromes of a small graph to the streaming kernel; same bits."""
     rng = np.random.default_rng(77)
     m, n = 48, 96
     H = np.zeros((m, n), np.int64)
@@ -330,12 +330,12 @@ def test_auto_kernel_choice_for_wide_matrices():
     assert dec.info("kernel_kind") == 2
     pv = rng.uniform(0.01, 0.1, n)
     prior = np.log((1 - pv) / pv)
-    syn = (((rng.random((20000, n)) < pv).astype(np.int64) @ H.T) % 2).astype(np.uint8)
+    syn = (((rng.random((140000, n)) < pv).astype(np.int64) @ H.T) % 2).astype(np.uint8)
     big = dec.decode(syn, prior, 30)
     assert dec.info("last_kernel") == 3
-    small = dec.decode(syn[:3000], prior, 30)
+    small = dec.decode(syn[:20000], prior, 30)
     assert dec.info("last_kernel") == 2
     for x, y in zip(big, small):
-        assert np.array_equal(x[:3000], y)
+        assert np.array_equal(x[:20000], y)
     o = oracle.decode_batch(H, syn[:1500], prior, 30)
     assert np.array_equal(big[0][:1500], o[0]) and np.array_equal(big[2][:1500], o[2])
