@@ -18,7 +18,8 @@ os.makedirs(dst, exist_ok=True)
 for a, b in (("bench.json", "bench_1gpu.json"), ("pytest.log", "pytest_gpu.log"), ("tune.log", "tune.txt"),
              ("tune_early.log", "tune_early_exit.txt"), ("misc.log", "misc_measurements.txt"),
              ("configs.log", "other_configs.txt"), ("diag_llr.log", "llr_drift_vs_oracle.txt"),
-             ("bench_2rank_rehearsal.json", "bench_2rank_gloo_rehearsal.json")):
+             ("bench_2rank_rehearsal.json", "bench_2rank_gloo_rehearsal.json"),
+             ("kernels.log", "other_kernels.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f"{pre}_{b}"))
 rows = list(csv.reader(open(os.path.join(src, "prof", "trace_kernel_stats.csv"))))

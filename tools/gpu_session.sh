@@ -13,6 +13,7 @@ echo "== diag"; timeout -k 10 300 python tools/diag_llr.py > $OUT/diag_llr.log 2
 echo "== tune"; timeout -k 10 600 python tools/tune.py > $OUT/tune.log 2>&1; tail -3 $OUT/tune.log
 echo "== tune early exit"; timeout -k 10 300 python tools/tune.py --early-exit --slots 2 4 7 --blocks 1 2 --batch 200000 > $OUT/tune_early.log 2>&1; tail -2 $OUT/tune_early.log
 echo "== misc"; timeout -k 10 600 python tools/measure_misc.py > $OUT/misc.log 2>&1; cat $OUT/misc.log
+echo "== kernels"; (timeout -k 10 300 python tools/bench_generic.py; timeout -k 10 300 python tools/bench_osd.py; timeout -k 10 300 python tools/ab_early.py; timeout -k 10 300 python tools/measure_latency.py) > $OUT/kernels.log 2>&1; grep -v amdgpu.ids $OUT/kernels.log
 echo "== other configs"; timeout -k 10 300 python tools/bench_configs.py > $OUT/configs.log 2>&1; cat $OUT/configs.log
 echo "== paper_results smoke"; timeout -k 10 300 python -m qldpc_amd.paper_results --codes 72 288 --p 0.05 0.02 --trials 50000 --max-iter 50 --out $OUT/paper_smoke > $OUT/paper_smoke.log 2>&1; tail -12 $OUT/paper_smoke.log
 echo "== bench"; timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json; tail -3 $OUT/bench.err
