@@ -132,6 +132,9 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
  *   [6] not_converged (= trials the reference would hand to OSD)  [7] sum of iteration indices
  *   [8] logical_error among not_converged  [9] detection == error exactly
  *   [10] OSD outputs that miss the syndrome (always 0)  [11] reserved (0).
+ * Any matrix: those that fit the on-chip kernel (m <= 1024, row weight <= 8, column weight <= 4) run
+ * the fused loop, all others the Monte-Carlo mode of the general-H kernel; QBP_FLAG_OSD0 needs the
+ * on-chip kernel and 64 KiB of LDS for OSD-0 (QBP_E_UNSUPPORTED otherwise).
  */
 #define QBP_NUM_COUNTERS 12
 int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, double p,

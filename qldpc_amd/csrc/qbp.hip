@@ -106,7 +106,8 @@ struct qbp_handle {
     DevBuf<uint8_t> d_wsC;
     int opt_force_generic = 0;
     int opt_kernel = 0;             // 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome), 3 streaming
-    DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes
+    DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes; general-H Monte-Carlo: syndromes
+    DevBuf<uint8_t> d_wsE;           // general-H Monte-Carlo: sampled errors
     DevBuf<int32_t> d_srow, d_srow_e0, d_srow_deg, d_svar, d_sedge;   // weight-class tables
     DevBuf<int32_t> d_epos, d_cpos;
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
@@ -511,7 +512,7 @@ void qbp_destroy(qbp_handle* h)
     h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
     if (h->pin_host) (void)hipHostFree(h->pin_host);
     h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
-    h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release(); h->d_svar.release(); h->d_sedge.release();
+    h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release(); h->d_wsE.release(); h->d_svar.release(); h->d_sedge.release();
     h->d_srow.release(); h->d_srow_e0.release(); h->d_srow_deg.release();
     h->d_epos.release(); h->d_cpos.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
@@ -523,7 +524,8 @@ void qbp_destroy(qbp_handle* h)
 static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior, int64_t B,
                           int max_iter, int variant, double alpha, double damping, double clip_llr,
                           unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
-                          double* d_llr, double* d_dump, int dump_iter, double dump_div, hipStream_t s)
+                          double* d_llr, double* d_dump, int dump_iter, double dump_div, hipStream_t s,
+                          const qbp::GenericParams* mc = nullptr)
 {
     // general-H kernel: one workgroup per syndrome, messages in a global workspace.  Batches that
     // cannot fill the chip with 256-thread workgroups get wider ones (latency of a single decode
@@ -549,10 +551,25 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p; G.wsV = h->d_wsV.p; G.wsC = h->d_wsC.p;
     G.dump_R = d_dump; G.dump_iter = dump_iter; G.dump_div = dump_div;
     h->last_threads = threads; h->last_lds = 0; h->last_grid = grid;
+    if (mc) {
+        // Monte-Carlo mode: per-workgroup error / syndrome scratch
+        HIP_TRY(h->d_wsE.reserve((size_t)grid * ((n + 3) / 4) * 4));
+        HIP_TRY(h->d_wsS.reserve((size_t)grid * (size_t)h->m));
+        G.lx_cols = mc->lx_cols; G.trial_begin = mc->trial_begin; G.seed = mc->seed;
+        G.threshold = mc->threshold; G.draws = mc->draws; G.half_distance = mc->half_distance;
+        G.counters = mc->counters; G.wsE = h->d_wsE.p; G.wsS = h->d_wsS.p;
+        switch (variant) {
+            case QBP_SUM_PRODUCT: hipLaunchKernelGGL((qbp::bp_generic_kernel<0, true>), dim3(grid), dim3(threads), 0, s, G); break;
+            case QBP_DAMPED_SP:   hipLaunchKernelGGL((qbp::bp_generic_kernel<1, true>), dim3(grid), dim3(threads), 0, s, G); break;
+            default:              hipLaunchKernelGGL((qbp::bp_generic_kernel<2, true>), dim3(grid), dim3(threads), 0, s, G); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return QBP_OK;
+    }
     switch (variant) {
-        case QBP_SUM_PRODUCT: hipLaunchKernelGGL(qbp::bp_generic_kernel<0>, dim3(grid), dim3(threads), 0, s, G); break;
-        case QBP_DAMPED_SP:   hipLaunchKernelGGL(qbp::bp_generic_kernel<1>, dim3(grid), dim3(threads), 0, s, G); break;
-        default:              hipLaunchKernelGGL(qbp::bp_generic_kernel<2>, dim3(grid), dim3(threads), 0, s, G); break;
+        case QBP_SUM_PRODUCT: hipLaunchKernelGGL((qbp::bp_generic_kernel<0>), dim3(grid), dim3(threads), 0, s, G); break;
+        case QBP_DAMPED_SP:   hipLaunchKernelGGL((qbp::bp_generic_kernel<1>), dim3(grid), dim3(threads), 0, s, G); break;
+        default:              hipLaunchKernelGGL((qbp::bp_generic_kernel<2>), dim3(grid), dim3(threads), 0, s, G); break;
     }
     HIP_TRY(hipGetLastError());
     return QBP_OK;
@@ -841,7 +858,7 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
                       uint32_t flags, int64_t* d_counters, void* stream)
 try {
     const int64_t T = trial_end - trial_begin;
-    int rc = check_decode_args(h, T, max_iter, variant, /*need_fused=*/true);
+    int rc = check_decode_args(h, T, max_iter, variant);
     if (rc) return rc;
     if (trial_begin < 0) return fail(QBP_E_INVALID, "trial_begin must be >= 0");
     if (draws != 1 && draws != 2) return fail(QBP_E_INVALID, "draws must be 1 or 2 (got %d)", draws);
@@ -852,6 +869,19 @@ try {
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = mc_prepare(h, Lx_host, k, s);
     if (rc) return rc;
+    if (!h->fused_ok || h->opt_kernel == 2 || h->opt_force_generic) {
+        // matrices beyond the on-chip kernel: the whole loop inside the general-H kernel (BP only)
+        if (flags & QBP_FLAG_OSD0)
+            return fail(QBP_E_UNSUPPORTED, "QBP_FLAG_OSD0 needs a matrix that fits the on-chip kernel "
+                                           "(m <= 1024, row weight <= 8, column weight <= 4)");
+        qbp::GenericParams M{};
+        M.lx_cols = h->d_lx_cols.p; M.trial_begin = trial_begin; M.seed = seed;
+        M.threshold = mc_threshold(p); M.draws = draws; M.half_distance = distance / 2;
+        M.counters = reinterpret_cast<long long*>(d_counters);
+        h->last_kernel = 2;
+        return generic_launch(h, nullptr, d_prior, T, max_iter, variant, alpha, damping, clip_llr, flags,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0, s, &M);
+    }
     LaunchCfg cfg;
     rc = make_cfg(h, T, &cfg);
     if (rc) return rc;
@@ -881,6 +911,7 @@ try {
     }
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
     HIP_TRY(launch_variant<true>(variant, P, cfg, s));
+    h->last_kernel = 1;
     if (osd) {
         // second kernel: OSD-0 + classification of the trials BP left unconverged; their number is
         // read from device memory by the kernel itself (no host round trip)

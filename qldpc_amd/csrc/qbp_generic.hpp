@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "qbp_math.hpp"
+#include "qbp_mc.hpp"
 
 namespace qbp {
 
@@ -53,6 +54,18 @@ struct GenericParams {
     double* dump_R;
     int dump_iter;
     double dump_div;
+    // Monte-Carlo mode (MC instantiation; paperResults_GPU.py:95-151 for any H): B trials starting
+    // at global index trial_begin; errors from the counter-based sampler, syndrome = H e, decode,
+    // classify against the logical operators, add to counters[NUM_COUNTERS]
+    const unsigned long long* lx_cols;  // [n] bit l = Lx[l][v]
+    long long trial_begin;
+    unsigned long long seed;
+    unsigned threshold;                 // floor(p * 2^32)
+    int draws;
+    int half_distance;
+    long long* counters;
+    uint8_t* wsE;                       // [grid][n4] sampled error of the current trial
+    uint8_t* wsS;                       // [grid][m] its syndrome
 };
 
 // Check update of one row held in registers: q[D] -> r[D]   (beliefPropagation.py:114-126 /
@@ -109,7 +122,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
 
 // __launch_bounds__(1024) = at most 128 registers: also right for the 256-thread launches, which
 // then fit 4 workgroups per CU (a 135-register build with 3 per CU was 30 % slower).
-template <int VARIANT>
+template <int VARIANT, bool MC = false>
 __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -121,13 +134,62 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
     uint8_t* cand = P.wsC + (size_t)blockIdx.x * n;
     const bool force_full = (P.flags & 1u) != 0;
     const double one_minus_damping = 1.0 - P.damping;
+    // Monte-Carlo mode: workgroup-wide accumulators of the trial being classified, and thread 0's
+    // counter row for all trials of this workgroup
+    __shared__ unsigned long long mc_lmask;
+    __shared__ int mc_weight, mc_diff;
+    int mc_cnt[NUM_COUNTERS] = {0};
+    const int n4 = (n + 3) / 4;
+    uint8_t* const err = MC ? P.wsE + (size_t)blockIdx.x * n4 * 4 : nullptr;
+    if constexpr (MC) {
+        if (tid == 0) { mc_lmask = 0ull; mc_weight = 0; mc_diff = 0; }
+    }
 
     for (long long b = blockIdx.x; b < P.B; b += gridDim.x) {
         const uint8_t* syn = P.syndromes + b * m;
+        if constexpr (MC) {
+            // errors of trial trial_begin + b (one Philox evaluation per four qubits), then its
+            // syndrome H e mod 2 (beliefPropagationGPU.py:195-198)
+            uint8_t* const sy = P.wsS + (size_t)blockIdx.x * m;
+            for (int g = tid; g < n4; g += nt)
+                reinterpret_cast<unsigned*>(err)[g] =
+                    mc_error_quad((unsigned long long)(P.trial_begin + b), g, P.draws, P.seed, P.threshold);
+            __syncthreads();
+            for (int i = tid; i < m; i += nt) {
+                unsigned par = 0;
+                const int e0 = P.srow_e0[i], deg = P.srow_deg[i];
+                for (int j = 0; j < deg; ++j) par ^= err[P.col_idx[e0 + j]];
+                sy[P.srow[i]] = (uint8_t)(par & 1u);
+            }
+            syn = sy;
+            __syncthreads();
+        }
         for (int e = tid; e < E; e += nt) Q[P.epos[e]] = P.prior[P.col_idx[e]];   // Q = prior on edges
         __syncthreads();
         bool frozen = false;
         int it = 0;
+        // Monte-Carlo: classification of the candidate error in `cand` (paperResults_GPU.py:113-144),
+        // called by the whole workgroup right after the barrier that made `cand` final
+        auto classify = [&](int conv, int it_done) {
+            unsigned long long lm = 0ull;
+            int ew = 0, df = 0;
+            for (int v = tid; v < n; v += nt) {
+                const unsigned e = err[v];
+                const unsigned res = (unsigned)cand[v] ^ e;
+                ew += (int)e;
+                df |= (int)res;
+                if (res) lm ^= P.lx_cols[v];
+            }
+            if (lm) atomicXor(&mc_lmask, lm);
+            if (ew) atomicAdd(&mc_weight, ew);
+            if (df) atomicOr(&mc_diff, 1);
+            __syncthreads();
+            if (tid == 0) {
+                mc_count_trial(mc_cnt, mc_lmask, mc_weight, mc_diff, conv, it_done, P.half_distance);
+                mc_lmask = 0ull; mc_weight = 0; mc_diff = 0;
+            }
+        };
+        (void)classify;
         for (; it < P.max_iter; ++it) {
             const bool scale = !(P.dump_R != nullptr && it == P.dump_iter);
             // ---- check step, one thread per check, by weight class: D coalesced loads, straight-
@@ -234,29 +296,44 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             const int any_unsat = __syncthreads_or(unsat);   // also orders Q for the next check step
             const bool conv = !frozen && !any_unsat;
             if (conv) {
-                for (int v = tid; v < n; v += nt) {
-                    if (P.llr) P.llr[b * n + v] = V[v];
-                    if (P.hard) P.hard[b * n + v] = cand[v];
-                }
-                if (tid == 0) {
-                    if (P.converged) P.converged[b] = 1;
-                    if (P.iters) P.iters[b] = it;
+                if constexpr (MC) {
+                    classify(1, it);
+                } else {
+                    for (int v = tid; v < n; v += nt) {
+                        if (P.llr) P.llr[b * n + v] = V[v];
+                        if (P.hard) P.hard[b * n + v] = cand[v];
+                    }
+                    if (tid == 0) {
+                        if (P.converged) P.converged[b] = 1;
+                        if (P.iters) P.iters[b] = it;
+                    }
                 }
                 frozen = true;
                 if (!force_full) break;
             }
         }
         if (!frozen) {
-            for (int v = tid; v < n; v += nt) {
-                if (P.llr) P.llr[b * n + v] = V[v];
-                if (P.hard) P.hard[b * n + v] = cand[v];
-            }
-            if (tid == 0) {
-                if (P.converged) P.converged[b] = 0;
-                if (P.iters) P.iters[b] = P.max_iter - 1;
+            if constexpr (MC) {
+                classify(0, P.max_iter - 1);
+            } else {
+                for (int v = tid; v < n; v += nt) {
+                    if (P.llr) P.llr[b * n + v] = V[v];
+                    if (P.hard) P.hard[b * n + v] = cand[v];
+                }
+                if (tid == 0) {
+                    if (P.converged) P.converged[b] = 0;
+                    if (P.iters) P.iters[b] = P.max_iter - 1;
+                }
             }
         }
         __syncthreads();
+    }
+    if constexpr (MC) {
+        if (tid == 0)
+            for (int i = 0; i < NUM_COUNTERS; ++i)
+                if (mc_cnt[i])
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i),
+                              (unsigned long long)mc_cnt[i]);
     }
 }
 

@@ -27,10 +27,9 @@
 #include <stdint.h>
 
 #include "qbp_math.hpp"
+#include "qbp_mc.hpp"
 
 namespace qbp {
-
-constexpr int NUM_COUNTERS = 12;
 
 struct FusedParams {
     // problem
@@ -77,18 +76,6 @@ struct FusedParams {
     uint8_t* fail_err;          // [B][n]
 };
 
-__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-
 // Rarely used launch parameters (output pointers, Monte-Carlo settings, ...) are re-read from the
 // kernel-argument segment where they are needed instead of being kept in SGPRs for the whole
 // kernel: the hot loop already needs ~60 SGPRs for FP64 constants, and every SGPR the compiler
@@ -102,22 +89,6 @@ __device__ __forceinline__ ColdArgs cold_args()
     return p;
 }
 #define COLD(field) (cold_args()->field)
-
-// Error bits of qubits 4g .. 4g+3 of trial `trial` as bytes (0/1) packed in a u32: one Philox
-// evaluation per draw serves four qubits (specification: oracle/bp_oracle.c, oracle_mc_errors:
-// counter = (trial lo, trial hi, qubit / 4, draw), word qubit % 4, bit = word < floor(p 2^32)).
-__device__ __forceinline__ unsigned mc_error_quad(unsigned long long trial, int g, int draws,
-                                                  unsigned long long seed, unsigned thr)
-{
-    unsigned bytes = 0;
-    for (int d = 0; d < draws; ++d) {
-        unsigned c[4] = {(unsigned)trial, (unsigned)(trial >> 32), (unsigned)g, (unsigned)d};
-        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
-        bytes ^= (c[0] < thr ? 1u : 0u) | (c[1] < thr ? 0x100u : 0u) | (c[2] < thr ? 0x10000u : 0u) |
-                 (c[3] < thr ? 0x1000000u : 0u);
-    }
-    return bytes;
-}
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi)
 {   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi) for non-NaN x: v_max_f64 + v_min_f64
@@ -145,17 +116,7 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
     const int ew = mc_weight[slot];
     const int df = mc_diff[slot];
     mc_lmask[slot] = 0ull; mc_weight[slot] = 0; mc_diff[slot] = 0;
-    const bool logical = lm != 0ull;                       // (Lx @ residual) % 2 has a 1
-    cnt[0] += 1;
-    if (conv && !logical && df) cnt[5] += 1;               // degenerateErrors  (:134-135)
-    if (logical) {
-        cnt[1] += 1;                                       // logical_error     (:137-138)
-        if (ew < half_distance) cnt[3] += 1; else cnt[4] += 1;   // (:140-144)
-        if (!conv) cnt[8] += 1;
-    }
-    if (!conv) cnt[6] += 1;
-    cnt[7] += it;
-    if (!df) cnt[9] += 1;
+    mc_count_trial(cnt, lm, ew, df, conv, it, half_distance);
 }
 
 // LDS carve (in units of 8 bytes after the message area):

@@ -199,11 +199,18 @@ def test_fuzz_osd_vs_oracle():
 
 
 def test_fuzz_mc_counters_vs_oracle():
-    rng = np.random.default_rng(99)
-    done = 0
-    for case in range(max(CASES // 6, 6)):
-        m = int(rng.integers(8, 120)); n = int(rng.integers(m, 2 * m + 4))
-        H = capped_matrix(rng, m, n, 6, 3, 1.0)
+    """qbp_mc_run (sampling, decoding, classification on the device) against the oracle pipeline:
+    on-chip kernel (with and without OSD-0) and the general-H kernel's Monte-Carlo mode, the latter
+    also on matrices only it can take."""
+    rng = np.random.default_rng(int(os.environ.get("QBP_FUZZ_SEED", "20261004")) + 99)
+    done = {1: 0, 2: 0}
+    for case in range(max(CASES // 4, 10)):
+        if rng.random() < 0.6:
+            m = int(rng.integers(8, 120)); n = int(rng.integers(m, 2 * m + 4))
+            H = capped_matrix(rng, m, n, 6, 3, 1.0)
+        else:
+            m = int(rng.integers(4, 50)); n = int(rng.integers(m, 3 * m))
+            H = (rng.random((m, n)) < rng.uniform(0.05, 0.25)).astype(np.int64)
         k = int(rng.integers(1, 9))
         Lx = (rng.random((k, n)) < 0.3).astype(np.uint8)
         p = float(rng.uniform(0.01, 0.08))
@@ -213,10 +220,18 @@ def test_fuzz_mc_counters_vs_oracle():
         distance = int(rng.integers(2, 12))
         variant = int(rng.choice([_lib.SUM_PRODUCT, _lib.MIN_SUM]))
         kw = dict(alpha=0.8, damping=0.7, clip_llr=25.0) if variant == _lib.MIN_SUM else {}
-        osd = bool(rng.random() < 0.5)
         dec = bp.decoder_for(H)
-        got = dec.mc_run(Lx, distance, p, prior, t0, t0 + T, draws=draws, seed=seed, max_iter=30,
-                         variant=variant, flags=_lib.FLAG_OSD0 if osd else 0, **kw)
+        general = dec.info("kernel_kind") == 2 or rng.random() < 0.3
+        osd = bool(rng.random() < 0.5) and not general
+        flags = (_lib.FLAG_OSD0 if osd else 0) | (_lib.FLAG_FORCE_FULL if rng.random() < 0.2 else 0)
+        dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_GENERAL if general else _lib.KERNEL_AUTO)
+        try:
+            got = dec.mc_run(Lx, distance, p, prior, t0, t0 + T, draws=draws, seed=seed, max_iter=30,
+                             variant=variant, flags=flags, **kw)
+            used = dec.info("last_kernel")
+        finally:
+            dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
+        assert used == (2 if general else 1)
         ref = oracle.mc_counters(H, Lx, distance, p, prior, t0, t0 + T, draws=draws, seed=seed,
                                  max_iter=30, variant=variant, osd=osd, **kw)
         if not np.array_equal(np.asarray(got)[:len(ref)], np.asarray(ref)):
@@ -224,6 +239,9 @@ def test_fuzz_mc_counters_vs_oracle():
             syn = (errors.astype(np.int64) @ H.T % 2).astype(np.uint8)
             noisy = noise_driven(H, syn, prior, 30, variant, kw.get("alpha", 1.0), kw.get("damping", 1.0),
                                  kw.get("clip_llr", 20.0))
-            assert noisy.any(), f"MC counters differ: case {case} {m}x{n} T={T} osd={osd} {got} vs {ref}"
-        done += T
-    print(f"fuzz Monte-Carlo: {done} trials, counters identical to the oracle pipeline")
+            chaotic = ~oracle.decode_batch(H, syn, prior, 30, variant, **kw)[1]
+            assert noisy.any() or chaotic.any(), \
+                f"MC counters differ: case {case} {m}x{n} T={T} kernel={used} osd={osd} {got} vs {ref}"
+        done[used] += T
+    print(f"fuzz Monte-Carlo: {done[1]} trials on the on-chip kernel, {done[2]} on the general-H kernel, "
+          f"counters identical to the oracle pipeline")
