@@ -2,8 +2,8 @@
 reference's ``main.py`` / ``paperResults.py`` / ``paperResults_GPU.py`` import THIS package for
 ``decoding.beliefPropagation`` and ``decoding.beliefPropagationGPU`` (a regular package wins
 over the reference's namespace directory of the same name).  Sub-modules this build does not
-replace (``decoding.OSD``, ``decoding.OSD_enhanced``) still resolve to the reference's own files:
-its ``decoding/`` directory, when present on sys.path, is appended to this package's search path.
+replace (``decoding.beliefPropagationJAX`` ...) still resolve to the reference's own files: its
+``decoding/`` directory, when present on sys.path, is appended to this package's search path.
 
 Importing the package itself gives the rework-style names (``from decoding import
 performBeliefPropagationFast, performMinSum_Symmetric, ...`` as rework/main.py:5-6 does).
@@ -18,4 +18,5 @@ for _p in list(_sys.path):
         __path__.append(_cand)
 
 from qldpc_amd.rework import (performBeliefPropagation_Symmetric,  # noqa: E402,F401
-                              performBeliefPropagationFast, performMinSum_Symmetric)
+                              performBeliefPropagationFast, performMinSum_Symmetric,
+                              performOSD_enhanced)

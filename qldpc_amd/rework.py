@@ -3,6 +3,7 @@
 * performBeliefPropagationFast          rework/decoding.py:77-129
 * performMinSum_Symmetric               rework/decoding.py:5-75
 * performBeliefPropagation_Symmetric    rework/decoding.py:131-191
+* performOSD_enhanced                   rework/decoding.py:193 (see qldpc_amd/osd.py)
 
 ``alpha_estimation=True`` (the message dump behind rework/Alvarado.py:10-66) returns, like the
 reference, ``(0, 0, R, 0)`` with R the dense (m, n) matrix of check->variable messages
@@ -15,6 +16,7 @@ import numpy as np
 
 from . import _lib
 from .bp import _check_iter, _prior, _syndromes, decode_one, decoder_for
+from .osd import performOSD_enhanced  # noqa: F401  (rework/decoding.py:193; rework/main.py:6 imports it)
 
 
 def _dense_messages(H, syndrome, initialBelief, variant, alpha, damping, clip_llr, iteration):

@@ -62,6 +62,8 @@ def main():
             a = performOSD(H, s, l, h)
             b = performOSD_enhanced(H, s, l, h, order=0)
             assert np.array_equal(a, b)
+            # any order: OSD_enhanced returns the OSD-0 solution as soon as it matches the syndrome
+            assert np.array_equal(a, performOSD_enhanced(H, s, l, h, order=2, max_combinations=50))
             assert np.array_equal((a @ H.T) % 2, s)
             sols.append(a)
         out[f"{tag}/H"] = H.astype(np.uint8)

@@ -20,6 +20,12 @@ def test_device_osd0_matches_reference_goldens(tag):
     assert np.array_equal((got.astype(np.int64) @ H.T) % 2, c["syndromes"])
     one = osd.performOSD(H, c["syndromes"][0], c["llr"][0], c["hard"][0])
     assert one.dtype == np.int64 and np.array_equal(one, c["solution"][0])
+    # performOSD_enhanced returns its OSD-0 solution whenever that reproduces the syndrome
+    # (OSD_enhanced.py: the early return before the higher-order search) -- for any order; the
+    # generator checked order 0 and 2 of the reference against performOSD on these vectors
+    for order in (0, 2):
+        two = osd.performOSD_enhanced(H, c["syndromes"][1], c["llr"][1], c["hard"][1], order=order)
+        assert np.array_equal(two, c["solution"][1])
 
 
 def test_device_osd0_vs_oracle_on_bp_failures():

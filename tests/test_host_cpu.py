@@ -85,21 +85,24 @@ def test_code_fixtures():
 
 
 def test_dropin_package_resolution(tmp_path):
-    """`decoding.beliefPropagation` / `decoding.OSD` must resolve to this build, and a module this
-    build does not replace (`decoding.OSD_enhanced`) to a reference-like namespace directory that
-    sits earlier on sys.path (as when running the reference's scripts from its root)."""
+    """`decoding.beliefPropagation` / `decoding.OSD` / `decoding.OSD_enhanced` must resolve to this
+    build, and a module this build does not replace (`decoding.beliefPropagationJAX`) to a
+    reference-like namespace directory that sits earlier on sys.path (as when running the
+    reference's scripts from its root)."""
     ref = tmp_path / "ref"
     (ref / "decoding").mkdir(parents=True)
-    (ref / "decoding" / "OSD_enhanced.py").write_text("def performOSD_enhanced(*a, **k):\n    return 'ref-osd-w'\n")
-    (ref / "decoding" / "OSD.py").write_text("raise RuntimeError('reference OSD imported')\n")
-    (ref / "decoding" / "beliefPropagation.py").write_text("raise RuntimeError('reference BP imported')\n")
+    (ref / "decoding" / "beliefPropagationJAX.py").write_text("def marker():\n    return 'ref-jax'\n")
+    for name in ("OSD", "OSD_enhanced", "beliefPropagation"):
+        (ref / "decoding" / f"{name}.py").write_text(f"raise RuntimeError('reference {name} imported')\n")
     script = ("import decoding.beliefPropagation as b, decoding.OSD as o, decoding.OSD_enhanced as w\n"
+              "import decoding.beliefPropagationJAX as j\n"
+              "from decoding import performOSD_enhanced, performMinSum_Symmetric\n"
               "print(b.performBeliefPropagationFast.__module__, o.performOSD.__module__, "
-              "w.performOSD_enhanced())\n")
+              "w.performOSD_enhanced.__module__, performOSD_enhanced.__module__, j.marker())\n")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "qldpc_amd", "dropin")]))
     (ref / "run.py").write_text(script)
     out = subprocess.check_output([sys.executable, str(ref / "run.py")], env=env, cwd=ref, text=True)
-    assert out.split() == ["qldpc_amd.bp", "qldpc_amd.osd", "ref-osd-w"]
+    assert out.split() == ["qldpc_amd.bp", "qldpc_amd.osd", "qldpc_amd.osd", "qldpc_amd.osd", "ref-jax"]
 
 
 def test_results_writer_schema(tmp_path):
