@@ -1,7 +1,8 @@
 """GPU: randomised cross-check of every device kernel against the CPU oracle and against each other.
 
 Random matrices (shapes the on-chip kernel takes, shapes only the general-H / streaming kernels
-take, empty rows, isolated variables, wide rows and columns), random priors, variants, iteration
+take, empty rows, isolated variables, wide rows and columns), random priors (some of them 0, +-inf
+or negative), variants, iteration
 limits, batch sizes and flags.  Bars:
 
 * the device kernels (automatic choice, general-H, streaming) return identical bits on EVERY input;
@@ -121,6 +122,9 @@ def test_fuzz_decode_kernels_vs_oracle():
         else:
             pv = rng.uniform(0.005, 0.3, n)
         prior = np.log((1 - pv) / pv)
+        if rng.random() < 0.15:                                   # extreme priors: p = 0.5, 0, 1, > 0.5
+            k = max(1, n // 8)
+            prior[rng.choice(n, k, replace=False)] = rng.choice([0.0, np.inf, -np.inf, -1.5, 700.0])
         err = (rng.random((B, n)) < pv * rng.uniform(0.3, 1.5)).astype(np.int64)
         syn = (err @ H.T % 2).astype(np.uint8)
         if rng.random() < 0.2:
