@@ -339,3 +339,42 @@ def test_auto_kernel_choice_for_wide_matrices():
         assert np.array_equal(x[:20000], y)
     o = oracle.decode_batch(H, syn[:1500], prior, 30)
     assert np.array_equal(big[0][:1500], o[0]) and np.array_equal(big[2][:1500], o[2])
+
+
+def test_distinct_handles_from_concurrent_threads():
+    """include/qbp.h: a handle is not thread-safe, distinct handles are independent -- four host
+    threads, each with its own handle (ctypes releases the GIL during the call), decode and run
+    the Monte-Carlo loop at the same time; results equal the serial ones."""
+    import threading
+    code = codes.load_code("[[144, 12, 12]]")
+    row_ptr, col_idx, m, n = bp.csr_from_H(code.Hx)
+    rng = np.random.default_rng(123)
+    prior = mc.prior_of(0.04, n)
+    jobs = [((rng.random((3000 + 500 * i, n)) < 0.04).astype(np.int64) @ code.Hx.T % 2).astype(np.uint8)
+            for i in range(4)]
+    ref_dec = bp.decoder_for(code.Hx)
+    want = [ref_dec.decode(s, prior, 50) for s in jobs]
+    want_mc = [ref_dec.mc_run(code.Lx, code.distance, 0.04, prior, 1000 * i, 1000 * i + 20000, seed=3)
+               for i in range(4)]
+    got, got_mc, errors = [None] * 4, [None] * 4, []
+
+    def work(i):
+        try:
+            dec = _lib.Decoder(row_ptr, col_idx, m, n, 0)
+            for _ in range(3):
+                got[i] = dec.decode(jobs[i], prior, 50)
+                got_mc[i] = dec.mc_run(code.Lx, code.distance, 0.04, prior, 1000 * i, 1000 * i + 20000, seed=3)
+            dec.close()
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        for x, y in zip(got[i], want[i]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(got_mc[i], want_mc[i])
