@@ -17,6 +17,8 @@
  *   - launches of ONE handle share its work counter and scratch workspaces: "_device" calls on
  *     the same handle must be ordered on one stream (or by events); to overlap launches on
  *     several streams use one handle per stream;
+ *   - every entry point makes the handle's device current for the duration of the call and
+ *     restores the calling thread's device before returning;
  *   - there is NO CPU fallback: without a usable HIP device qbp_create fails with
  *     QBP_E_NO_DEVICE.
  */

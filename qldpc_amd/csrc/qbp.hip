@@ -53,6 +53,22 @@ int fail(int code, const char* fmt, ...)
 constexpr int DC_SMALL = 6, DV_SMALL = 3;
 constexpr int DC_WIDE = 8, DV_WIDE = 4;
 
+// Makes `device` current for the lifetime of the object and restores the caller's device
+// afterwards (entry points must not leave a host thread on another GPU than they found it on).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceScope(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err != hipSuccess) { prev = -1; err = hipSuccess; }
+        if (prev != device) err = hipSetDevice(device); else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -393,7 +409,8 @@ try {
                     de == hipSuccess ? "device count 0" : hipGetErrorString(de));
     if (device < 0 || device >= ndev)
         return fail(QBP_E_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    DeviceScope on_device(device);
+    HIP_TRY(on_device.err);
 
     struct Guard {                       // destroys a half-built handle on every early exit
         qbp_handle* h;
@@ -505,7 +522,7 @@ QBP_ABI_CATCH
 void qbp_destroy(qbp_handle* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceScope on_device(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     h->d_tab_var.release(); h->d_tab_nbr.release(); h->d_tab_writer.release(); h->d_iso.release();
     h->d_work_counter.release(); h->d_syn.release(); h->d_hard.release(); h->d_conv.release();
@@ -631,7 +648,8 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     if (B == 0) return QBP_OK;
     if (!d_syndromes || !d_prior) return fail(QBP_E_INVALID, "null input pointer");
     if (B > (int64_t)1 << 40) return fail(QBP_E_INVALID, "B too large");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // kernel choice: the on-chip kernel when the matrix fits; otherwise one workgroup per syndrome
     // (general-H), except for small graphs in batches that fill the chip with one LANE per syndrome,
@@ -678,7 +696,8 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
     if (!syndromes || !prior) return fail(QBP_E_INVALID, "null input pointer");
     for (int v = 0; v < h->n; ++v)
         if (prior[v] != prior[v]) return fail(QBP_E_INVALID, "prior[%d] is NaN (+-inf are legal)", v);
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     const size_t m = h->m, n = h->n, b = (size_t)B;
     {
         // Small calls (the reference's one-syndrome-per-call usage, paperResults.py:71): inputs and
@@ -750,7 +769,8 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
     if (variant == QBP_SUM_PRODUCT) variant = QBP_DAMPED_SP;   // same update with alpha=damping=1
     if (B == 0) return QBP_OK;
     if (!syndromes || !prior || !messages) return fail(QBP_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     const size_t m = h->m, n = h->n, b = (size_t)B, E = (size_t)std::max(h->E, 1);
     HIP_TRY(h->d_syn.reserve(b * m));
     HIP_TRY(h->d_prior.reserve(n));
@@ -826,7 +846,8 @@ int qbp_osd0_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0");
     if (B == 0) return QBP_OK;
     if (!d_syndromes || !d_llr || !d_hard || !d_solution) return fail(QBP_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     qbp::OsdParams O{};
     O.count = B; O.syndromes = d_syndromes; O.llr = d_llr; O.hard = d_hard; O.solution = d_solution;
     return osd_launch(h, O, B, static_cast<hipStream_t>(stream));
@@ -839,7 +860,8 @@ int qbp_osd0_batch(qbp_handle* h, const uint8_t* syndromes, const double* llr, c
     if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0");
     if (B == 0) return QBP_OK;
     if (!syndromes || !llr || !hard || !solution) return fail(QBP_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     const size_t m = h->m, n = h->n, b = (size_t)B;
     HIP_TRY(h->d_syn.reserve(b * m));
     HIP_TRY(h->d_llr.reserve(b * n));
@@ -870,7 +892,8 @@ try {
     if (!(p >= 0.0 && p <= 1.0)) return fail(QBP_E_INVALID, "p = %g out of [0, 1]", p);
     if (!d_prior || !d_counters) return fail(QBP_E_INVALID, "null pointer");
     if (T == 0) return QBP_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = mc_prepare(h, Lx_host, k, s);
     if (rc) return rc;
@@ -940,7 +963,8 @@ int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, do
 {
     if (!h) return fail(QBP_E_INVALID, "null handle");
     if (!prior || !counters) return fail(QBP_E_INVALID, "null pointer");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     hipStream_t s = h->stream;
     HIP_TRY(h->d_prior.reserve(h->n));
     HIP_TRY(h->d_counters.reserve(qbp::NUM_COUNTERS));
@@ -965,7 +989,8 @@ try {
     if (!errors) return fail(QBP_E_INVALID, "errors is null");
     if (draws != 1 && draws != 2) return fail(QBP_E_INVALID, "draws must be 1 or 2");
     if (T == 0) return QBP_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     hipStream_t s = h->stream;
     rc = mc_prepare(h, nullptr, 0, s);
     if (rc) return rc;
@@ -1039,7 +1064,8 @@ int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int6
 {
     if (!h || !x || !y || count < 0 || kind < 0 || kind > 3) return fail(QBP_E_INVALID, "bad arguments");
     if (count == 0) return QBP_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     HIP_TRY(h->d_mathx.reserve((size_t)count));
     HIP_TRY(h->d_mathy.reserve((size_t)count));
     hipStream_t s = h->stream;
