@@ -550,8 +550,14 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     // of a large matrix: checks / variables per thread shrink 4x).
     const bool wide = B < (long long)h->num_cu * 2;
     const int threads = wide ? std::min(1024, std::max(256, (std::max(h->m, 64) + 63) / 64 * 64)) : 256;
-    const int grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * (wide ? 1 : 4)));
     const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
+    // 4 resident workgroups per CU; 3 or 2 when the message workspaces of 4 would overflow the
+    // 256 MiB Infinity Cache (2592 x 7776 space-time matrix, 400 KB per syndrome: 8.6e4 syndromes/s
+    // with 2 per CU against 7.7e4 with 4; fewer than 2 loses more occupancy than it saves traffic)
+    int per_cu = wide ? 1 : 4;
+    if (h->opt_blocks_per_cu > 0) per_cu = h->opt_blocks_per_cu;
+    else while (per_cu > 2 && (double)h->num_cu * per_cu * (double)(2 * E * 8 + n * 9) > 256e6) --per_cu;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * per_cu));
     HIP_TRY(h->d_wsQ.reserve((size_t)grid * E));
     HIP_TRY(h->d_wsR.reserve((size_t)grid * E));
     HIP_TRY(h->d_wsV.reserve((size_t)grid * n));
