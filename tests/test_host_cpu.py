@@ -1,5 +1,6 @@
 """CPU: host logic and the C-ABI library surface (no compute calls without a GPU)."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -210,3 +211,27 @@ def test_nan_prior_rejected_by_the_shim():
     with pytest.raises(ValueError, match="NaN"):
         bp._prior([0.5, float("nan"), 1.0], 3)
     assert np.isinf(bp._prior([np.inf, -np.inf, 1.0], 3)[:2]).all()
+
+
+def test_bench_accounting_and_committed_line():
+    """bench.py: the algorithmic-byte formula of SURVEY 8(d) and the contract keys of the JSON line
+    (checked on the line committed under profiles/)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # [[288,12,18]]: E = 864, m = 144, n = 288 -> 27 648 B per iteration, 2 741 B of I/O per syndrome
+    assert bench.algorithmic_bytes(864, 144, 288, 1, 0) == 27648
+    assert bench.algorithmic_bytes(864, 144, 288, 50, 1) == 1382400 + 2741
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_1gpu.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["scaling"] == "weak" and line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["unit"] == "GB/s" and r["traffic"] is not None
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c
+    assert line["value"] > 1e6            # the north star's floor
