@@ -125,7 +125,8 @@ struct qbp_handle {
     DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes; general-H Monte-Carlo: syndromes
     DevBuf<uint8_t> d_wsE;           // general-H Monte-Carlo: sampled errors
     DevBuf<int32_t> d_srow, d_srow_e0, d_srow_deg, d_svar, d_sedge;   // weight-class tables
-    DevBuf<int32_t> d_epos, d_cpos;
+    DevBuf<int32_t> d_epos, d_cpos, d_long_edge_row;
+    DevBuf<double> d_wsL;
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
@@ -218,7 +219,7 @@ struct HostTables {
     // streaming kernel: checks / variables sorted by weight class (qbp_stream.hpp)
     std::vector<int32_t> srow, srow_e0, srow_deg, svar, sedge;
     // general-H kernel: class-blocked transposed message layout (qbp_generic.hpp)
-    std::vector<int32_t> epos, cpos;
+    std::vector<int32_t> epos, cpos, long_edge_row;
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
@@ -304,7 +305,10 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
         }
         T.row_base[RC + 1] = base;                      // longer checks: entries contiguous
         for (int i = T.row_off[RC + 1]; i < T.row_off[RC + 2]; ++i)
-            for (int j = 0; j < T.srow_deg[i]; ++j) T.epos[T.srow_e0[i] + j] = base++;
+            for (int j = 0; j < T.srow_deg[i]; ++j) {
+                T.epos[T.srow_e0[i] + j] = base++;
+                T.long_edge_row.push_back(i - T.row_off[RC + 1]);
+            }
     }
     for (int q = 0; q < E; ++q) T.cpos[q] = T.epos[T.col_edge[q]];
     for (int k = 0; k <= CC + 1; ++k) {
@@ -445,6 +449,7 @@ try {
     up(h->d_col_edge, T.col_edge);
     up(h->d_epos, T.epos);
     up(h->d_cpos, T.cpos);
+    up(h->d_long_edge_row, T.long_edge_row);
     std::copy(std::begin(T.row_base), std::end(T.row_base), h->row_base);
     up(h->d_srow, T.srow);
     up(h->d_srow_e0, T.srow_e0);
@@ -532,7 +537,7 @@ void qbp_destroy(qbp_handle* h)
     h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
     h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release(); h->d_wsE.release(); h->d_svar.release(); h->d_sedge.release();
     h->d_srow.release(); h->d_srow_e0.release(); h->d_srow_deg.release();
-    h->d_epos.release(); h->d_cpos.release();
+    h->d_epos.release(); h->d_cpos.release(); h->d_long_edge_row.release(); h->d_wsL.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
@@ -567,6 +572,12 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     G.col_idx = h->d_col_idx.p; G.col_ptr = h->d_col_ptr.p;
     G.srow = h->d_srow.p; G.srow_e0 = h->d_srow_e0.p; G.srow_deg = h->d_srow_deg.p;
     G.epos = h->d_epos.p; G.cpos = h->d_cpos.p;
+    G.long_edge_row = h->d_long_edge_row.p;
+    {
+        const size_t n_long = (size_t)(h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 2] - h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 1]);
+        HIP_TRY(h->d_wsL.reserve((size_t)grid * 3 * std::max<size_t>(n_long, 1)));
+        G.wsL = h->d_wsL.p;
+    }
     std::copy(std::begin(h->row_off), std::end(h->row_off), G.row_off);
     std::copy(std::begin(h->row_base), std::end(h->row_base), G.row_base);
     G.syndromes = d_syndromes; G.prior = d_prior; G.B = B; G.max_iter = max_iter; G.flags = flags;

@@ -25,7 +25,10 @@ struct GenericParams {
     // Message layout of one syndrome ("class-blocked, transposed"): checks are sorted by row weight
     // (stable; build_tables in qbp.hip); the cnt checks of weight D occupy one block in which entry
     // j of the i-th such check sits at row_base[D] + j * cnt + i, so that consecutive threads (one
-    // check each) touch consecutive doubles.  Checks of weight > 8 keep their entries contiguous.
+    // check each) touch consecutive doubles.  Checks of weight > 8 keep their entries contiguous,
+    // behind the blocks: positions [row_base[9], E) = the "long" edges; their transcendental work is
+    // done one thread per EDGE (long_edge_row = index of the check among the long ones), only the
+    // sequential row product / minimum search runs one thread per check.
     const int32_t* srow;        // [m] check index, sorted by weight class
     const int32_t* srow_e0;     // [m] first CSR edge of that check
     const int32_t* srow_deg;    // [m] its weight
@@ -33,6 +36,8 @@ struct GenericParams {
     const int32_t* cpos;        // [E] CSC slot (column-major, ascending check) -> position
     int row_off[GENERIC_MAX_ROW_CLASS + 3];    // class boundaries in srow (0 .. 8, > 8)
     int row_base[GENERIC_MAX_ROW_CLASS + 2];   // first position of each class block
+    const int32_t* long_edge_row;   // [E - row_base[9]]
+    double* wsL;                // [grid][3 * number of long checks] row product / (sprod, min1, min2)
     const uint8_t* syndromes;
     const double* prior;
     long long B;
@@ -208,47 +213,60 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
             QBP_ROW_CLASS(5) QBP_ROW_CLASS(6) QBP_ROW_CLASS(7) QBP_ROW_CLASS(8)
 #undef QBP_ROW_CLASS
-            for (int i = P.row_off[RC + 1] + tid; i < P.row_off[RC + 2]; i += nt) {   // weight > 8
-                const int deg = P.srow_deg[i];
-                const int p0 = P.epos[P.srow_e0[i]];            // entries contiguous from here
-                const unsigned sbit = syn[P.srow[i]] & 1u;
-                if constexpr (VARIANT == 2) {
-                    double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
-                    int min1_j = -1;
-                    bool anynan = false;
-                    for (int j = 0; j < deg; ++j) {
-                        const double x = Q[p0 + j];
-                        sprod *= x < 0.0 ? -1.0 : 1.0;
-                        anynan |= x != x;
-                        const double a = __builtin_fabs(x);
-                        if (a < min1) { min1 = a; min1_j = j; }
+            // ---- checks of weight > 8: the per-edge work (tanh; division + atanh) one thread per
+            //      edge, the sequential part (np.prod in ascending column order / argmin and second
+            //      minimum) one thread per check, two workgroup barriers in between
+            const int first_long = P.row_off[RC + 1], n_long = P.row_off[RC + 2] - first_long;
+            if (n_long > 0) {                                           // uniform
+                const int lbase = P.row_base[RC + 1], n_ledges = E - lbase;
+                double* const L = P.wsL + (size_t)blockIdx.x * 3 * n_long;
+                if constexpr (VARIANT != 2) {
+                    for (int k = tid; k < n_ledges; k += nt) R[lbase + k] = tanh_half(Q[lbase + k]);
+                    __syncthreads();
+                }
+                for (int i = tid; i < n_long; i += nt) {
+                    const int deg = P.srow_deg[first_long + i];
+                    const int p0 = P.epos[P.srow_e0[first_long + i]];   // entries contiguous from here
+                    if constexpr (VARIANT == 2) {
+                        double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
+                        int min1_j = -1;
+                        bool anynan = false;
+                        for (int j = 0; j < deg; ++j) {
+                            const double x = Q[p0 + j];
+                            sprod *= x < 0.0 ? -1.0 : 1.0;
+                            anynan |= x != x;
+                            const double a = __builtin_fabs(x);
+                            if (a < min1) { min1 = a; min1_j = j; }
+                        }
+                        if (anynan) sprod = __builtin_nan("");
+                        for (int j = 0; j < deg; ++j) {
+                            const double a = __builtin_fabs(Q[p0 + j]);
+                            if (j != min1_j && a < min2) min2 = a;
+                        }
+                        L[3 * i] = sprod; L[3 * i + 1] = min1; L[3 * i + 2] = min2;
+                    } else {
+                        double prod = 1.0;
+                        for (int j = 0; j < deg; ++j) prod = (j == 0) ? R[p0] : prod * R[p0 + j];
+                        L[3 * i] = prod;
                     }
-                    if (anynan) sprod = __builtin_nan("");
-                    for (int j = 0; j < deg; ++j) {
-                        const double a = __builtin_fabs(Q[p0 + j]);
-                        if (j != min1_j && a < min2) min2 = a;
-                    }
-                    const double as = sbit ? -P.alpha : P.alpha;
-                    for (int j = 0; j < deg; ++j) {
-                        const double x = Q[p0 + j];
+                }
+                __syncthreads();
+                for (int k = tid; k < n_ledges; k += nt) {
+                    const int i = P.long_edge_row[k];
+                    const unsigned sbit = syn[P.srow[first_long + i]] & 1u;
+                    if constexpr (VARIANT == 2) {
+                        const double x = Q[lbase + k];
                         const double sg = x < 0.0 ? -1.0 : 1.0;
-                        const double mag = (__builtin_fabs(x) == min1) ? min2 : min1;
-                        R[p0 + j] = (as * (sprod * sg)) * mag;
-                    }
-                } else {
-                    double prod = 1.0;
-                    for (int j = 0; j < deg; ++j) {
-                        const double t = tanh_half(Q[p0 + j]);
-                        R[p0 + j] = t;                             // R holds tanh for now
-                        prod = (j == 0) ? t : prod * t;
-                    }
-                    for (int j = 0; j < deg; ++j) {
-                        const double t = R[p0 + j];
+                        const double mag = (__builtin_fabs(x) == L[3 * i + 1]) ? L[3 * i + 2] : L[3 * i + 1];
+                        const double as = sbit ? -P.alpha : P.alpha;
+                        R[lbase + k] = (as * (L[3 * i] * sg)) * mag;
+                    } else {
+                        const double t = R[lbase + k];
                         const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
-                        double po = div_nr(prod, ts);
+                        double po = div_nr(L[3 * i], ts);
                         po = sbit ? -po : po;
                         const double x = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
-                        R[p0 + j] = (VARIANT == 1 && scale) ? x * P.alpha : x;
+                        R[lbase + k] = (VARIANT == 1 && scale) ? x * P.alpha : x;
                     }
                 }
             }
