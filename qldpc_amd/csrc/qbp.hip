@@ -553,12 +553,15 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     // general-H kernel: one workgroup per syndrome, messages in a global workspace.  Batches that
     // cannot fill the chip with 256-thread workgroups get wider ones (latency of a single decode
     // of a large matrix: checks / variables per thread shrink 4x).
-    const bool wide = B < (long long)h->num_cu * 2;
-    const int threads = wide ? std::min(1024, std::max(256, (std::max(h->m, 64) + 63) / 64 * 64)) : 256;
+    // Workgroup shape: 256 threads, 4 workgroups per CU.  Wider (up to 1024 threads, one per CU)
+    // when the batch cannot fill the chip anyway (single decodes of large matrices: the checks /
+    // variables per thread shrink 4x) and when one syndrome's messages exceed 256 KB: then four
+    // workspaces per CU overflow the 256 MiB Infinity Cache and more threads per syndrome is the
+    // way to more loads in flight (2592 x 7776 space-time matrix, 400 KB: 1.2e5 syndromes/s with
+    // 1024 threads against 8.5e4 with 4 x 256; [[288,12,18]], 14 KB: 1.3e6 against 2.5e6).
     const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
-    // 4 resident workgroups per CU; 3 or 2 when the message workspaces of 4 would overflow the
-    // 256 MiB Infinity Cache (2592 x 7776 space-time matrix, 400 KB per syndrome: 8.6e4 syndromes/s
-    // with 2 per CU against 7.7e4 with 4; fewer than 2 loses more occupancy than it saves traffic)
+    const bool wide = B < (long long)h->num_cu * 2 || 2 * E * 8 + n * 9 >= 256 * 1024;
+    const int threads = wide ? std::min(1024, std::max(256, (std::max(h->m, 64) + 63) / 64 * 64)) : 256;
     int per_cu = wide ? 1 : 4;
     if (h->opt_blocks_per_cu > 0) per_cu = h->opt_blocks_per_cu;
     else while (per_cu > 2 && (double)h->num_cu * per_cu * (double)(2 * E * 8 + n * 9) > 256e6) --per_cu;

@@ -245,8 +245,17 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         }
                         L[3 * i] = sprod; L[3 * i + 1] = min1; L[3 * i + 2] = min2;
                     } else {
+                        // eight loads in flight, then the multiplications in ascending order
                         double prod = 1.0;
-                        for (int j = 0; j < deg; ++j) prod = (j == 0) ? R[p0] : prod * R[p0 + j];
+                        int j = 0;
+                        for (; j + 8 <= deg; j += 8) {
+                            double a[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) a[u] = R[p0 + j + u];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) prod = (j + u == 0) ? a[0] : prod * a[u];
+                        }
+                        for (; j < deg; ++j) prod = (j == 0) ? R[p0] : prod * R[p0 + j];
                         L[3 * i] = prod;
                     }
                 }
