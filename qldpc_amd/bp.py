@@ -16,6 +16,7 @@ priors must not be NaN (+-inf are fine).
 from __future__ import annotations
 
 import hashlib
+import os
 
 import numpy as np
 
@@ -32,7 +33,9 @@ except Exception:  # pragma: no cover
 
 _DECODERS: dict = {}
 _MAX_CACHED = 16
-DEVICE = 0          # HIP device used by the module-level functions (one process per GPU)
+# HIP device used by the module-level functions (one process per GPU: set QBP_DEVICE per rank, or
+# assign qldpc_amd.bp.DEVICE before the first call)
+DEVICE = int(os.environ.get("QBP_DEVICE", "0"))
 
 
 def csr_from_H(H):
