@@ -92,3 +92,24 @@ def test_paper_results_driver_end_to_end(tmp_path, capsys):
         assert res[name]["BPs_fault"] == [0, 0]
     # double draw at p = 0.05 on [[72,12,6]] with OSD-0: LER around 0.6 (effective p = 0.095)
     assert 0.45 < res["[[72, 12, 6]]"]["ler"][0] < 0.75
+
+
+def test_bench_two_rank_path(tmp_path):
+    """The N > 1 code path of bench.py (rank env, barrier, max-over-ranks timing, all-reduce of the
+    counts, rank-0 JSON line), rehearsed with two ranks sharing this GPU over gloo (RCCL refuses two
+    ranks on one device); the real multi-GPU run uses the same code with backend nccl."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--share-device",
+           "--batch", "8000", "--mode", "forced", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    # (two ranks time-share one GPU and synchronise over gloo: not a performance number)
+    assert line["value"] > 1e5 and line["config"]["syndromes_per_gpu_per_step"] == 8000
