@@ -65,7 +65,6 @@ def test_shard_ranges_tile():
 def test_philox_known_answer():
     """Philox4x32-10 known-answer vectors (Random123 kat_vectors): the oracle's generator is the
     published algorithm, so device == oracle (test_gpu_mc) pins the device to it as well."""
-    import ctypes as C
     # counter (0,0,0,0), key (0,0) -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8
     # exposed indirectly: threshold compare on word v&3 of counter (trial, trial>>32, v>>2, draw)
     L = oracle.lib()
