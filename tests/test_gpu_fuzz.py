@@ -199,6 +199,8 @@ def test_fuzz_osd_vs_oracle():
             assert np.array_equal(sol[i], ref), f"OSD-0 differs: case {case} {kind} {m}x{n}"
             assert np.array_equal(sol[i].astype(np.int64) @ H.T % 2, syn[i])
         done += B
+        if (case + 1) % 500 == 0:
+            print(f"  ... {case + 1} OSD cases", flush=True)
     print(f"fuzz OSD-0: {done} solutions identical to the oracle")
 
 
@@ -247,5 +249,7 @@ def test_fuzz_mc_counters_vs_oracle():
             assert noisy.any() or chaotic.any(), \
                 f"MC counters differ: case {case} {m}x{n} T={T} kernel={used} osd={osd} {got} vs {ref}"
         done[used] += T
+        if (case + 1) % 100 == 0:
+            print(f"  ... {case + 1} Monte-Carlo cases", flush=True)
     print(f"fuzz Monte-Carlo: {done[1]} trials on the on-chip kernel, {done[2]} on the general-H kernel, "
           f"counters identical to the oracle pipeline")
