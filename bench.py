@@ -2,18 +2,36 @@
 """Headline benchmark: syndromes/s of the [[288,12,18]] sum-product BP decode at 50 iterations.
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+``--gpus N`` with N > 1 starts itself: unless a launcher already set WORLD_SIZE, the process spawns
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`` as a
+child BEFORE touching torch or HIP (qldpc_amd/launch.py) and exits with its status.  Under an external
+launcher (the driver's torch.distributed.run) it is simply one of the ranks.
 
 One "step" = one pass of the hot path (qbp_decode_batch_device, include/qbp.h) over one batch of
-synthetic syndromes that is already resident in HBM: BASELINE.json configs[3], [[288,12,18]],
-sum-product, max_iter 50, 1M trials over 8 GPUs = 125 000 syndromes per GPU (weak scaling).
-`value` is measured in mode M2 of SURVEY.md 8(d): every syndrome runs all 50 iterations
-(QBP_FLAG_FORCE_FULL; outputs are still those of the first converged iteration), which is what
-"at 50 BP iters" means and what the algorithmic-byte roofline is defined on.  The reference's own
-semantics (return at the first syndrome match, mode M1) is timed too and reported under
-"early_exit".  PyTorch only provides device memory, the stream, events and torch.distributed.
+synthetic syndromes already resident in HBM: BASELINE.json configs[3], [[288,12,18]], sum-product,
+max_iter 50, 1M trials over 8 GPUs = 125 000 syndromes per GPU (weak scaling).  `value` is measured
+in mode M2 of SURVEY.md 8(d): every syndrome runs all 50 iterations (QBP_FLAG_FORCE_FULL; outputs are
+still those of the first converged iteration).  Everything else in the line is measured by this run:
+
+* ``roofline``       the binding resource of the on-chip kernel is FP64 vector-ALU issue, not HBM.
+                     Instruction mix per wave-iteration: read from the machine code of the library
+                     this process loaded (tools/valu_mix.py); issue rate of each instruction class:
+                     measured now by tools/ubench/valu_rates.hip; frac = t_min / t_kernel.
+* ``hbm_effective``  SURVEY 8(d)'s algorithmic bytes over the kernel time (exceeds the HBM peak: the
+                     messages it counts never leave the CU) -- kept as the north star's own yardstick.
+* ``early_exit``     reference semantics (mode M1); ``stress_p010`` forced-50 on a p = 0.10 batch BP
+                     cannot decode (M2 stress of SURVEY 8(d)); ``sustained`` >= 10 s of back-to-back
+                     forced-50 launches and the shader clock right after; ``hbm_streamed_variant`` the
+                     one-lane-per-syndrome kernel whose messages do go through HBM; ``dropin_api`` the
+                     reference's own calling pattern (paperResults_GPU.py:95-144) through the Python
+                     mirror, host arrays and PCIe included; ``cpu_baseline`` the CPU oracle on this
+                     box's cores (+ the reference's Python figure, a labelled constant measured in the
+                     build container: the reference cannot travel to the GPU box).
+PyTorch only provides device memory, the stream, events and torch.distributed.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -29,6 +47,12 @@ BATCH_PER_GPU = 125_000
 MAX_ITER = 50
 P_ERR = 0.01
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+# decoding/beliefPropagation.py:88 performBeliefPropagationFast on [[288,12,18]], forced 50
+# iterations, one core of the build container's 8-vCPU Xeon @ 2.1 GHz (re-measured in round 1 with
+# time.perf_counter over 200 syndromes; SURVEY.md 6.2 had 24.1): the reference is single-threaded
+# Python and cannot run on the GPU box, so this is a constant with its provenance, not a measurement
+# of this run.
+REFERENCE_PYTHON_SYN_PER_S = 19.7
 
 
 def algorithmic_bytes(E, m, n, iters_total, B):
@@ -61,7 +85,80 @@ def cpu_baseline(code, syndromes, prior, budget_s=12.0):
         dtm = time.perf_counter() - t0
         out["multi_thread"] = {"value": nmt / dtm, "unit": "syndromes/s", "cores": threads,
                                "sample": f"{nmt} syndromes, {dtm:.1f} s, OpenMP over syndromes"}
+    out["reference_python"] = {
+        "value": REFERENCE_PYTHON_SYN_PER_S, "unit": "syndromes/s", "cores": 1, "kind": "reference",
+        "measured_by_this_run": False,
+        "sample": "decoding/beliefPropagation.py:88 performBeliefPropagationFast, [[288,12,18]], forced "
+                  "50 iterations, 200 syndromes, 1 core of the BUILD container (8-vCPU Xeon @ 2.1 GHz); "
+                  "the reference cannot travel to the GPU box"}
     return out
+
+
+# ---- FP64 vector-ALU roofline, measured by this run -------------------------------------------------
+def valu_rates(device, waves_per_simd=4):
+    """{class: wave-instructions/s, whole chip} from tools/ubench/valu_rates.hip, plus the clock."""
+    so = os.path.join(ROOT, "tools", "ubench", "libvalu_rates.so")
+    if not os.path.exists(so):
+        raise RuntimeError(f"{so} missing: run __graft_entry__.build()")
+    L = ctypes.CDLL(so)
+    L.ubench_class_name.restype = ctypes.c_char_p
+    L.ubench_valu_rate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    L.ubench_clock_ghz.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    rates, c = {}, 0
+    while True:
+        name = L.ubench_class_name(c)
+        if not name:
+            break
+        r = ctypes.c_double()
+        rc = L.ubench_valu_rate(device, c, waves_per_simd, ctypes.byref(r))
+        if rc != 0:
+            raise RuntimeError(f"ubench_valu_rate({name.decode()}) failed: {rc}")
+        rates[name.decode()] = r.value
+        c += 1
+    return rates
+
+
+def shader_clock_ghz(device):
+    so = os.path.join(ROOT, "tools", "ubench", "libvalu_rates.so")
+    L = ctypes.CDLL(so)
+    L.ubench_clock_ghz.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    g = ctypes.c_double()
+    return g.value if L.ubench_clock_ghz(device, ctypes.byref(g)) == 0 else None
+
+
+def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, num_cu):
+    """frac = (sum over classes of instructions / measured issue rate of that class) / kernel time."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_mix
+    res = valu_mix.analyse(lib_path, [kernel_symbol])
+    if len(res) != 1:
+        raise RuntimeError(f"{len(res)} kernels match {kernel_symbol!r} in {lib_path}")
+    name, mix = next(iter(res.items()))
+    rates = valu_rates(device)
+    per_class = {}
+    t_min = 0.0
+    for cls, n in mix["valu_by_class"].items():
+        rate = rates.get(cls) or rates["alu_b32" if cls.endswith("b32") else "fma_f64"]
+        t = n * wave_iterations / rate
+        per_class[cls] = {"per_wave_iteration": n, "wave_insts_per_s_peak": rate, "seconds": t}
+        t_min += t
+    n_total = mix["valu_total"]
+    achieved = n_total * wave_iterations * 64 / kernel_s               # lane-instructions / s
+    frac = t_min / kernel_s
+    return {
+        "bound": "fp64_valu", "achieved": achieved / 1e12, "peak": achieved / frac / 1e12,
+        "unit": "Tlane-instr/s", "frac": frac, "traffic": None,
+        "kernel": name, "kernel_ms": kernel_s * 1e3,
+        "valu_insts_per_wave_iteration": n_total, "wave_iterations_per_launch": wave_iterations,
+        "issue_seconds_by_class": per_class,
+        "fma_f64_peak_TFLOPs": rates["fma_f64"] * 64 * 2 / 1e12,
+        "spec_peak_TFLOPs_fp64_vector": num_cu * 4 * 16 * 2 * 2.4e9 / 1e12,
+        "how": "instruction mix: static, from the loaded libqbp.so (tools/valu_mix.py: main loop of the "
+               "kernel minus the once-per-syndrome regions); issue rates: measured in this run at 4 waves "
+               "per SIMD (tools/ubench/valu_rates.hip); peak = achieved / frac, i.e. the rate at which "
+               "this mix would issue with every slot used; traffic (HBM bytes from PMC counters) cannot "
+               "be collected from inside the run: see profiles/ and DESIGN.md section 4",
+    }
 
 
 def main():
@@ -74,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("both", "forced"), default="both",
                     help="forced: only the headline mode (profiling runs)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
+                    help="length of the back-to-back forced-50 leg (0 = skip; skipped in --mode forced)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 "
                          "path on a box with fewer GPUs than ranks)")
@@ -82,6 +181,9 @@ def main():
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     args = ap.parse_args()
+
+    from qldpc_amd import launch
+    launch.maybe_self_launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -93,15 +195,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_device:
         local_rank = 0
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    full = args.mode == "both"
 
     code = codes.load_code(CODE)
     m, n = code.Hx.shape
@@ -116,11 +220,15 @@ def main():
     # synthetic data of the reference's shape: i.i.d. Bernoulli(p) errors
     # (beliefPropagationGPU.py:195), syndrome = H e mod 2 (:198), prior = log((1-p)/p) (main.py:18).
     # Each rank draws its own shard (seed = rank): no data-path collective.
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    errors = (torch.rand((B, n), generator=g, device=dev) < args.p)
     Ht = torch.from_numpy(code.Hx.T.astype(np.float32)).to(dev)
-    syndromes = (errors.float() @ Ht).remainder_(2).to(torch.uint8).contiguous()
+
+    def draw(p, seed):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        e = (torch.rand((B, n), generator=g, device=dev) < p)
+        return (e.float() @ Ht).remainder_(2).to(torch.uint8).contiguous()
+
+    syndromes = draw(args.p, 1234 + rank)
     prior = torch.full((n,), float(np.log((1 - args.p) / args.p)), dtype=torch.float64, device=dev)
     hard = torch.empty((B, n), dtype=torch.uint8, device=dev)
     conv = torch.empty((B,), dtype=torch.uint8, device=dev)
@@ -128,8 +236,9 @@ def main():
     llr = torch.empty((B, n), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev)
 
-    def step(flags):
-        dec.decode_device(syndromes.data_ptr(), prior.data_ptr(), B, MAX_ITER, _lib.SUM_PRODUCT,
+    def step(flags, syn=None, pr=None):
+        dec.decode_device((syndromes if syn is None else syn).data_ptr(),
+                          (prior if pr is None else pr).data_ptr(), B, MAX_ITER, _lib.SUM_PRODUCT,
                           1.0, 1.0, 20.0, flags, hard.data_ptr(), conv.data_ptr(),
                           iters.data_ptr(), llr.data_ptr(), stream.cuda_stream)
 
@@ -138,16 +247,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(flags, steps, warmup):
+    def timed(flags, steps, warmup, syn=None, pr=None):
         for _ in range(warmup):
-            step(flags)
+            step(flags, syn, pr)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(steps)]
         barrier()
         t0 = time.perf_counter()
         for a, b in evs:
-            a.record(stream)
-            step(flags)
+            a.record(stream)             # HIP events on the stream the kernel is launched on
+            step(flags, syn, pr)
             b.record(stream)
         counts = torch.stack([conv.sum(dtype=torch.int64), iters.sum(dtype=torch.int64)])
         if world > 1:
@@ -164,24 +273,80 @@ def main():
 
     # ---- M2: forced 50 iterations (headline) ------------------------------------------------
     wall, kernel_ms, counts = timed(_lib.FLAG_FORCE_FULL, args.steps, args.warmup)
+    clock_after_headline = shader_clock_ghz(local_rank)
     value = world * B * args.steps / wall
     bytes_per_launch = algorithmic_bytes(E, m, n, B * MAX_ITER, B)
     geometry = {"threads_per_block": dec.info("threads"), "grid": dec.info("grid"),
                 "lds_bytes": dec.info("lds_bytes")}
+    kernel_kind = dec.info("last_kernel")
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
+
+    # per-rank kernel times and the reduce on its own
+    multi = None
+    if world > 1:
+        km = torch.zeros(world, dtype=torch.float64, device=dev)
+        km[rank] = kernel_ms
+        dist.all_reduce(km)
+        t = torch.zeros(2, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            dist.all_reduce(t)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(t)
+        torch.cuda.synchronize(dev)
+        multi = {"n_ranks_seen": dist.get_world_size(), "backend": args.backend,
+                 "kernel_ms_per_rank": [float(x) for x in km.tolist()],
+                 "all_reduce_us": (time.perf_counter() - t0) / 20 * 1e6}
+
     # ---- M1: reference semantics (early exit) -----------------------------------------------
-    early = None
-    if args.mode == "both":
+    early = stress = sustained = None
+    if full:
         wall1, kernel_ms1, counts1 = timed(0, args.steps, 1)
         bytes1 = algorithmic_bytes(E, m, n, counts1[1] / world + B, B)
         early = {"value": world * B * args.steps / wall1, "unit": "syndromes/s",
                  "mean_iterations": counts1[1] / (world * B) + 1.0, "kernel_ms": kernel_ms1,
                  "converged_fraction": counts1[0] / (world * B),
                  "effective_GBps": bytes1 / (kernel_ms1 * 1e-3) / 1e9}
+        # ---- M2 stress: p = 0.10 syndromes BP does not decode -----------
+        syn10 = draw(0.10, 4321 + rank)
+        prior10 = torch.full((n,), float(np.log(0.9 / 0.1)), dtype=torch.float64, device=dev)
+        steps10 = max(3, args.steps // 4)
+        wall10, kernel_ms10, counts10 = timed(_lib.FLAG_FORCE_FULL, steps10, 1, syn10, prior10)
+        stress = {"value": world * B * steps10 / wall10, "unit": "syndromes/s", "p": 0.10,
+                  "kernel_ms": kernel_ms10, "converged_fraction": counts10[0] / (world * B),
+                  "ratio_to_headline_kernel_ms": kernel_ms10 / kernel_ms,
+                  "note": "same launch on a batch BP cannot decode: no data-dependent shortcut in forced mode"}
+        del syn10
+        # ---- sustained: back-to-back forced-50 launches for >= N seconds -------------------------
+        if args.sustained_seconds > 0:
+            n_launch = max(args.steps, int(np.ceil(args.sustained_seconds / (kernel_ms * 1e-3))))
+            barrier()
+            t0 = time.perf_counter()
+            marks = []
+            for i in range(n_launch):
+                step(_lib.FLAG_FORCE_FULL)
+                if i % max(1, n_launch // 10) == 0:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(stream)
+                    marks.append((i, ev))
+            barrier()
+            wall_s = time.perf_counter() - t0
+            clock_s = shader_clock_ghz(local_rank)
+            if world > 1:
+                w = torch.tensor([wall_s], dtype=torch.float64, device=dev)
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                wall_s = float(w.item())
+            seg = [(marks[j + 1][0] - marks[j][0]) * B / (marks[j][1].elapsed_time(marks[j + 1][1]) * 1e-3)
+                   for j in range(len(marks) - 1)]
+            sustained = {"value": world * B * n_launch / wall_s, "unit": "syndromes/s", "seconds": wall_s,
+                         "launches": n_launch, "ratio_to_headline": world * B * n_launch / wall_s / value,
+                         "rank0_rate_by_tenth": [float(x) for x in seg],
+                         "shader_clock_GHz_right_after": clock_s}
 
     # ---- the HBM-streamed design point (qbp_stream.hpp), same workload, forced 50 ----------------
     streamed = None
-    if args.mode == "both":
+    if full and world == 1:
         # one lane per syndrome needs >= 256 CUs x 16 waves x 64 lanes to fill the chip: its own batch
         Bs = 262144
         reps = -(-Bs // B)
@@ -204,48 +369,41 @@ def main():
                 ms_s.append(a.elapsed_time(b))
         dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
         kernel_ms_s = float(np.mean(ms_s))
+        step(_lib.FLAG_FORCE_FULL)
+        torch.cuda.synchronize(dev)
         same = bool(torch.equal(hard_s[:B], hard) and torch.equal(iters_s[:B], iters))
         del syn_s, hard_s, conv_s, iters_s, llr_s
         bytes_s = algorithmic_bytes(E, m, n, Bs * MAX_ITER, Bs)
         ach_s = bytes_s / (kernel_ms_s * 1e-3)
-        tr = None
-        pf = os.path.join(ROOT, "profiles", "r01_stream_pmc_summary.json")
-        if os.path.exists(pf):
-            try:
-                dd = json.load(open(pf))
-                tr = {"physical_over_algorithmic": dd["physical_over_algorithmic"],
-                      "physical_GBps_profiled": dd["physical_GBps"],
-                      "source": "profiles/r01_stream_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, 262144-syndrome launch)"}
-            except Exception:
-                tr = None
         streamed = {"kernel": "qbp::bp_stream_kernel<0>", "syndromes_per_launch": Bs,
                     "value": Bs / (kernel_ms_s * 1e-3), "unit": "syndromes/s per GPU",
                     "kernel_ms": kernel_ms_s, "same_results_as_default_kernel": same,
                     "roofline": {"bound": "hbm", "achieved": ach_s / 1e9, "peak": HBM_PEAK / 1e9,
-                                 "unit": "GB/s", "frac": ach_s / HBM_PEAK, "traffic": tr},
+                                 "unit": "GB/s", "frac": ach_s / HBM_PEAK, "traffic": None},
                     "note": "one lane per syndrome, messages streamed through HBM ([edge][syndrome] SoA): "
-                            "here the algorithmic bytes ARE the physical traffic; not the default kernel"}
+                            "here the algorithmic bytes ARE the physical traffic (PMC: profiles/); not the "
+                            "default kernel"}
+
+    # ---- the reference's calling pattern through the drop-in API (host arrays, PCIe included) -----
+    dropin = None
+    if full and world == 1:
+        dropin = dropin_leg(code, local_rank)
 
     if rank == 0:
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("bytes_per_launch_forced50")
-            except Exception:
-                traffic = None
-        valu = None
-        pf = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pf):
-            try:
-                dd = json.load(open(pf))["derived"]
-                valu = {"note": "the physically binding resource (FP64 vector ALU), from the PMC passes in "
-                                "profiles/r01_pmc_summary.json -- not measured by this run",
-                        "valu_busy_fraction": dd["valu_busy_fraction"],
-                        "valu_insts_per_syndrome_iteration": dd["valu_insts_per_syndrome_iteration"],
-                        "shader_clock_GHz": dd["shader_clock_GHz"]}
-            except Exception:
-                valu = None
+        dc = 6 if (dec.info("max_row_deg") <= 6 and dec.info("max_col_deg") <= 3) else 8
+        symbol = f"bp_fused_kernelILi{dc}ELi{3 if dc == 6 else 4}ELi0ELb0ELb1E"
+        S = max(1, geometry["threads_per_block"] // m)
+        waves = (geometry["threads_per_block"] + 63) // 64
+        wave_iters = B * MAX_ITER / S * waves
+        try:
+            if kernel_kind != 1:
+                raise RuntimeError(f"the headline ran kernel kind {kernel_kind}, not the on-chip kernel")
+            roof = valu_roofline(_lib.LIB_PATH, symbol, local_rank, wave_iters, kernel_ms * 1e-3,
+                                 dec.info("num_cu"))
+            roof["shader_clock_GHz_right_after"] = clock_after_headline
+        except Exception as ex:             # a bench line without a roofline is still a bench line
+            roof = {"bound": "fp64_valu", "achieved": None, "peak": None, "unit": "Tlane-instr/s",
+                    "frac": None, "traffic": None, "error": f"{type(ex).__name__}: {ex}"}
         out = {
             "metric": "syndromes/sec at 50 BP iters, [[288,12,18]] code",
             "value": value, "unit": "syndromes/s", "n_gpus": world, "steps": args.steps,
@@ -255,17 +413,23 @@ def main():
             "config": {"workload": "BASELINE.json configs[3]: [[288,12,18]] BB code, sum-product BP, "
                                    "max_iter 50, every syndrome runs all 50 iterations (mode M2)",
                        "syndromes_per_gpu_per_step": B, "p": args.p, "max_iter": MAX_ITER,
-                       "sharding": f"{world} x independent syndrome shards, RCCL all-reduce of counts",
+                       "sharding": f"{world} x independent syndrome shards, one all-reduce of counts "
+                                   f"({'RCCL' if args.backend == 'nccl' else args.backend})",
                        **geometry},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "qbp::bp_fused_kernel<6,3,0,false,true,1024,1>",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "effective bandwidth: messages stay in LDS/registers, physical HBM "
-                                 "traffic is only syndrome/LLR I/O; the physical limiter is FP64 VALU"},
+            "roofline": roof,
+            "hbm_effective": {"achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK, "kernel_ms": kernel_ms,
+                              "algorithmic_bytes_per_launch": bytes_per_launch,
+                              "note": "SURVEY 8(d) algorithmic bytes / kernel time: NOT a roofline for this "
+                                      "kernel (messages stay in LDS/registers, so the figure may exceed the "
+                                      "HBM peak); physical HBM traffic is syndrome/LLR I/O only (PMC: "
+                                      "profiles/)"},
+            "multi_gpu": multi,
             "early_exit": early,
-            "valu_f64": valu,
+            "stress_p010": stress,
+            "sustained": sustained,
             "hbm_streamed_variant": streamed,
+            "dropin_api": dropin,
             "converged_fraction": counts[0] / (world * B),
         }
         if not args.no_cpu_baseline and world == 1:
@@ -274,6 +438,65 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def dropin_leg(code, device, p=0.05, batch=5000, batches=4, max_iter=150):
+    """paperResults_GPU.py:95-144 as its author would run it after swapping the import: host numpy
+    sampling (two draws XORed), performBeliefPropagationBatch(code, syndromes[5000], prior,
+    maxIter=150) with host arrays in and out, performOSD per BP failure, classification in numpy --
+    next to the device-resident loop (qbp_mc_run) on the same trial count."""
+    import torch
+
+    from qldpc_amd import _lib, bp, mc, osd
+    H, Lx = code.Hx, code.Lx.astype(np.int64)
+    n = code.n
+    rng = np.random.default_rng(0)
+    prior = np.array([np.log((1 - p) / p)] * n)
+    bp.performBeliefPropagationBatch(H, np.zeros((8, H.shape[0]), np.int8), prior, maxIter=2)   # warm-up
+    t_gen = t_bp = t_osd = t_cls = 0.0
+    logical = osd_calls = 0
+    for _ in range(batches):
+        t0 = time.perf_counter()
+        e1, s1 = bp.generate_errors_and_syndromes_batch(H, p, batch, rng)
+        e2, s2 = bp.generate_errors_and_syndromes_batch(H, p, batch, rng)
+        errors, syndromes = (e1 + e2) % 2, (s1 + s2) % 2
+        t1 = time.perf_counter()
+        det, conv, llrs = bp.performBeliefPropagationBatch(H, syndromes, prior, maxIter=max_iter)
+        t2 = time.perf_counter()
+        det = det.astype(np.int64)
+        for i in np.flatnonzero(~conv):
+            det[i] = osd.performOSD(H, syndromes[i], llrs[i], det[i])
+            osd_calls += 1
+        t3 = time.perf_counter()
+        residual = (det + errors) % 2
+        logical += int(((residual @ Lx.T) % 2).any(1).sum())
+        t4 = time.perf_counter()
+        t_gen += t1 - t0; t_bp += t2 - t1; t_osd += t3 - t2; t_cls += t4 - t3
+    T = batch * batches
+    # the same number of trials through the device-resident loop (sampling + BP + OSD-0 + classification)
+    dec = bp.decoder_for(H, device=device)
+    dec.mc_run(code.Lx, code.distance, p, prior, 0, 1000, draws=2, max_iter=max_iter, flags=_lib.FLAG_OSD0)
+    t0 = time.perf_counter()
+    c = dec.mc_run(code.Lx, code.distance, p, prior, 0, T, draws=2, max_iter=max_iter, flags=_lib.FLAG_OSD0)
+    t_mc = time.perf_counter() - t0
+    Tbig = 1 << 20
+    t0 = time.perf_counter()
+    dec.mc_run(code.Lx, code.distance, p, prior, 0, Tbig, draws=2, max_iter=max_iter, flags=_lib.FLAG_OSD0)
+    t_mc_big = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return {"pattern": "paperResults_GPU.py:95-144 (two draws, batch 5000, maxIter 150, OSD on BP failures)",
+            "p": p, "trials": T, "max_iter": max_iter,
+            "trials_per_s_decode_call_only": T / t_bp,
+            "trials_per_s_bp_plus_osd_calls": T / (t_bp + t_osd),
+            "trials_per_s_whole_loop": T / (t_gen + t_bp + t_osd + t_cls),
+            "seconds": {"host_sampling": t_gen, "performBeliefPropagationBatch": t_bp,
+                        "performOSD_calls": t_osd, "host_classification": t_cls},
+            "osd_calls": osd_calls, "ler": logical / T,
+            "device_resident_qbp_mc_run": {"trials_per_s_same_trial_count": T / t_mc,
+                                           "trials_per_s_1M_trials": Tbig / t_mc_big,
+                                           "ler": int(c[1]) / T},
+            "note": "host-array signature: H2D of syndromes and D2H of hard/converged/LLR (8n bytes per trial) "
+                    "inside the timed call"}
 
 
 if __name__ == "__main__":

@@ -55,8 +55,14 @@ enum {
 enum {
     QBP_FLAG_FORCE_FULL = 1u, /* run all max_iter iterations for every syndrome; outputs are still
                                  those of the first converged iteration (bench mode "M2") */
-    QBP_FLAG_OSD0 = 2u        /* qbp_mc_run only: trials BP does not converge on go through OSD-0
+    QBP_FLAG_OSD0 = 2u,       /* qbp_mc_run only: trials BP does not converge on go through OSD-0
                                  (decoding/OSD.py) before classification, as paperResults.py:73-77 */
+    QBP_FLAG_PAIRWISE_COLSUM = 4u /* column sums in the order of np.sum over the gathered 1-D column,
+                                 i.e. numpy's pairwise summation from 8 entries per column on: the
+                                 loop form performBeliefPropagation (decoding/beliefPropagation.py:68).
+                                 The dense forms (:129, rework/decoding.py) accumulate row by row =
+                                 left to right, the default.  Only matrices with a column of weight
+                                 >= 8 see a difference (they run on the general-H kernel). */
 };
 #define QBP_MC_OSD_MAX_TRIALS (1 << 20) /* per qbp_mc_run call with QBP_FLAG_OSD0 (record buffers) */
 
@@ -111,7 +117,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
  * return value of the reference, restricted to the edges of H:
  *   QBP_MIN_SUM   rework/decoding.py:58-59   R_new / alpha at iteration 0
  *   QBP_DAMPED_SP rework/decoding.py:168-169 R (before scaling by alpha) at iteration 10
- * (QBP_SUM_PRODUCT is treated as QBP_DAMPED_SP: pass alpha = damping = 1.)
+ * (QBP_SUM_PRODUCT: the plain update, i.e. alpha = damping = 1 and no LLR clip whatever is passed.)
  */
 int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
                        int32_t variant, double alpha, double damping, double clip_llr,
@@ -175,6 +181,7 @@ enum {
     QBP_OPT_FORCE_GENERIC = 4,   /* 1 = use the general-H kernel even where the on-chip one fits */
     QBP_OPT_KERNEL = 5,          /* 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome),
                                     3 streaming (lane per syndrome, messages in HBM)          */
+    QBP_OPT_GENERAL_THREADS = 6, /* general-H kernel: threads per workgroup (0 = auto)        */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
     QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 on-chip, 2 general-H, 3 streaming */
     QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109,

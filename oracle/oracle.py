@@ -25,6 +25,7 @@ VARIANT_SUM_PRODUCT = 0     # beliefPropagation.py:88-144 / rework/decoding.py:7
 VARIANT_DAMPED_SP = 1       # rework/decoding.py:131-191
 VARIANT_MIN_SUM = 2         # rework/decoding.py:5-75
 FLAG_FORCE_FULL = 1
+FLAG_PAIRWISE_COLSUM = 4   # column sums as np.sum(R[checks_v, v]) (loop form, beliefPropagation.py:68)
 
 
 def build(force: bool = False) -> str:
@@ -54,6 +55,8 @@ def lib():
             C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p]
         L.oracle_osd0.restype = C.c_int
         L.oracle_osd0.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 5
+        L.oracle_np_pairwise_sum.restype = C.c_double
+        L.oracle_np_pairwise_sum.argtypes = [C.c_void_p, C.c_int32]
         L.oracle_mc_threshold.restype = C.c_uint32
         L.oracle_mc_threshold.argtypes = [C.c_double]
         _LIB = L
@@ -91,6 +94,12 @@ def decode_batch(H, syndromes, prior, max_iter=50, variant=0, alpha=1.0, damping
     if rc != 0:
         raise ValueError(f"oracle_bp_decode_batch failed: {rc}")
     return hard, conv.astype(bool), iters, llr
+
+
+def np_pairwise_sum(a):
+    """The oracle's restatement of ``np.sum`` over a contiguous 1-D float64 array."""
+    a = np.ascontiguousarray(a, np.float64)
+    return float(lib().oracle_np_pairwise_sum(a.ctypes.data, len(a)))
 
 
 def mc_errors(n, p, draws, seed, trial_begin, T):

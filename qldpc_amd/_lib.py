@@ -18,12 +18,13 @@ LIB_PATH = os.environ.get("QBP_LIB_PATH") or os.path.join(_HERE, "csrc", "libqbp
 SUM_PRODUCT, DAMPED_SP, MIN_SUM = 0, 1, 2
 FLAG_FORCE_FULL = 1
 FLAG_OSD0 = 2
+FLAG_PAIRWISE_COLSUM = 4     # np.sum order of the loop form (beliefPropagation.py:68)
 MC_OSD_MAX_TRIALS = 1 << 20
 NUM_COUNTERS = 12
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
                  "degenerateErrors", "not_converged", "sum_iterations",
                  "logical_error_not_converged", "exact_recoveries", "osd_invalid", "reserved1")
-OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_FORCE_GENERIC, OPT_KERNEL = 1, 2, 4, 5
+OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_FORCE_GENERIC, OPT_KERNEL, OPT_GENERAL_THREADS = 1, 2, 4, 5, 6
 KERNEL_AUTO, KERNEL_ON_CHIP, KERNEL_GENERAL, KERNEL_STREAM = 0, 1, 2, 3
 INFO = dict(m=100, n=101, edges=102, max_row_deg=103, max_col_deg=104, kernel_kind=105,
             threads=106, lds_bytes=107, grid=108, num_cu=109, last_kernel=110)

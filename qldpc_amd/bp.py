@@ -32,6 +32,7 @@ except Exception:  # pragma: no cover
         return hashlib.blake2b(buf, digest_size=16).digest()
 
 _DECODERS: dict = {}
+_BY_ID: dict = {}          # id(H) -> (weakref to H or None, fingerprint, key): skips the content hash
 _MAX_CACHED = 16
 # HIP device used by the module-level functions (one process per GPU: set QBP_DEVICE per rank, or
 # assign qldpc_amd.bp.DEVICE before the first call)
@@ -62,15 +63,37 @@ def csr_from_H(H):
     return row_ptr, np.ascontiguousarray(cols, np.int32), int(A.shape[0]), int(A.shape[1])
 
 
+def _fingerprint(H, sparse):
+    """Cheap identity check of an array we have hashed before: same object, same buffer, same
+    shape / dtype / strides, and not writeable (a writeable array may have changed in place -- it is
+    re-hashed every time, as before)."""
+    if sparse:
+        return None
+    a = H if isinstance(H, np.ndarray) else None
+    if a is None or a.flags.writeable:
+        return None
+    return (a.__array_interface__["data"][0], a.shape, a.dtype.str, a.strides)
+
+
 def decoder_for(H, device=None) -> _lib.Decoder:
     """Decoder handle for H, cached on the matrix content (the reference re-derives the graph on
-    every call; here that happens once per code)."""
+    every call; here that happens once per code).
+
+    The cache only holds references: an evicted Decoder stays usable by whoever still holds it and
+    its device handle is destroyed when the last reference goes (``Decoder.__del__``).  A handle is
+    not thread-safe (include/qbp.h): threads that decode the same matrix concurrently should each
+    build their own ``_lib.Decoder``; this cache hands every caller the same one."""
     device = DEVICE if device is None else device
     try:
         from scipy.sparse import issparse
         sparse = issparse(H)
     except Exception:  # pragma: no cover
         sparse = False
+    fp = _fingerprint(H, sparse)
+    if fp is not None:
+        hit = _BY_ID.get((id(H), device))
+        if hit is not None and hit[0]() is H and hit[1] == fp and hit[2] in _DECODERS:
+            return _DECODERS[hit[2]]
     if sparse:
         S = H.tocsr()
         key = ("s", S.shape, _digest(np.ascontiguousarray(S.indptr)),
@@ -84,8 +107,16 @@ def decoder_for(H, device=None) -> _lib.Decoder:
         row_ptr, col_idx, m, n = csr_from_H(H)
         dec = _lib.Decoder(row_ptr, col_idx, m, n, device)
         if len(_DECODERS) >= _MAX_CACHED:
-            _DECODERS.pop(next(iter(_DECODERS))).close()
+            _DECODERS.pop(next(iter(_DECODERS)))       # drop the reference only (see docstring)
         _DECODERS[key] = dec
+    if fp is not None:
+        import weakref
+        if len(_BY_ID) > 4 * _MAX_CACHED:
+            _BY_ID.clear()
+        try:
+            _BY_ID[(id(H), device)] = (weakref.ref(H), fp, key)
+        except TypeError:  # pragma: no cover
+            pass
     return dec
 
 
@@ -120,12 +151,12 @@ def _check_iter(maxIter):
 
 
 def decode_one(H, syndrome, initialBelief, maxIter, variant=_lib.SUM_PRODUCT, alpha=1.0,
-               damping=1.0, clip_llr=20.0):
+               damping=1.0, clip_llr=20.0, flags=0):
     """(hard int8[n], converged bool, llr float64[n], iteration int) for one syndrome."""
     dec = decoder_for(H)
     syn = _syndromes(syndrome, dec.m, batch=False)
     hard, conv, iters, llr = dec.decode(syn[None, :].astype(np.uint8), _prior(initialBelief, dec.n),
-                                        _check_iter(maxIter), variant, alpha, damping, clip_llr)
+                                        _check_iter(maxIter), variant, alpha, damping, clip_llr, flags)
     return hard[0].astype(np.int8), bool(conv[0]), llr[0], int(iters[0])
 
 
@@ -149,7 +180,10 @@ def performBeliefPropagation(H, syndrome, initialBelief, verbose=True, plotPath=
         except Exception:  # pragma: no cover
             dense = np.asarray(H, dtype=np.float64)
         plotGraph(dense, path=plotPath)
-    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter)
+    # the loop form sums each gathered column with np.sum (:68): numpy's pairwise order from 8
+    # entries per column on -- the dense forms accumulate row by row
+    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter,
+                                     flags=_lib.FLAG_PAIRWISE_COLSUM)
     if conv and verbose:
         print(f"Error found at iteration {it}: {hard}")                      # :82
     return hard, conv, llr

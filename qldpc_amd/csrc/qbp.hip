@@ -126,7 +126,10 @@ struct qbp_handle {
     DevBuf<uint8_t> d_wsE;           // general-H Monte-Carlo: sampled errors
     DevBuf<int32_t> d_srow, d_srow_e0, d_srow_deg, d_svar, d_sedge;   // weight-class tables
     DevBuf<int32_t> d_epos, d_cpos, d_long_edge_row;
-    DevBuf<double> d_wsL;
+    DevBuf<int32_t> d_vpos, d_vrow, d_lcol_ptr;      // general-H kernel: column-class tables
+    DevBuf<double> d_wsL, d_prior_sorted;
+    int gcol_base[qbp::GENERIC_MAX_COL_CLASS + 2] = {0};
+    int opt_threads = 0;            // general-H kernel: threads per workgroup (0 = auto)
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
@@ -203,7 +206,7 @@ size_t fused_lds_bytes(int dc, int m, int n, int S)
     const size_t slot_stride = (size_t)dc * m + 2;
     size_t lds = ((size_t)S * slot_stride + (size_t)dc * m + 2 * (size_t)S) * 8 +
                  (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
-                 (size_t)S * (((size_t)n + 3) / 4) * 4;
+                 2 * (size_t)S * (((size_t)n + 3) / 4) * 4;     // err_lds[2][S][n4] (Monte-Carlo builds)
     return (lds + 15) & ~(size_t)15;
 }
 
@@ -220,6 +223,8 @@ struct HostTables {
     std::vector<int32_t> srow, srow_e0, srow_deg, svar, sedge;
     // general-H kernel: class-blocked transposed message layout (qbp_generic.hpp)
     std::vector<int32_t> epos, cpos, long_edge_row;
+    std::vector<int32_t> vpos, vrow, lcol_ptr;         // general-H kernel, variables by column class
+    int gcol_base[qbp::GENERIC_MAX_COL_CLASS + 2] = {0};
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
@@ -323,6 +328,39 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
     }
     T.col_off[CC + 2] = n;
     if (T.sedge.empty()) T.sedge.push_back(0);
+    // general-H kernel: per column entry the message position and the SORTED position of its check,
+    // blocked and transposed by column-weight class (qbp_generic.hpp); long columns contiguous
+    static_assert(qbp::GENERIC_MAX_COL_CLASS == qbp::STREAM_MAX_COL_CLASS, "shared column classes");
+    {
+        std::vector<int32_t> wpos((size_t)m, 0);
+        for (int w = 0; w < m; ++w) wpos[T.srow[w]] = w;
+        T.vpos.assign((size_t)std::max(E, 1), 0);
+        T.vrow.assign((size_t)std::max(E, 1), 0);
+        int base = 0;
+        for (int k = 1; k <= CC; ++k) {
+            const int cnt = T.col_off[k + 1] - T.col_off[k];
+            T.gcol_base[k] = base;
+            for (int i = 0; i < cnt; ++i) {
+                const int v = T.svar[T.col_off[k] + i];
+                for (int j = 0; j < k; ++j) {
+                    T.vpos[(size_t)base + (size_t)j * cnt + i] = T.cpos[T.col_ptr[v] + j];
+                    T.vrow[(size_t)base + (size_t)j * cnt + i] = wpos[cols[v][j].first];
+                }
+            }
+            base += k * cnt;
+        }
+        T.gcol_base[CC + 1] = base;
+        for (int i = T.col_off[CC + 1]; i < T.col_off[CC + 2]; ++i) {
+            const int v = T.svar[i];
+            T.lcol_ptr.push_back(base);
+            for (size_t j = 0; j < cols[v].size(); ++j) {
+                T.vpos[base] = T.cpos[T.col_ptr[v] + (int)j];
+                T.vrow[base] = wpos[cols[v][j].first];
+                ++base;
+            }
+        }
+        T.lcol_ptr.push_back(base);
+    }
     return QBP_OK;
 }
 
@@ -392,6 +430,128 @@ void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg)
 
 }  // namespace
 
+template <int VARIANT, bool MC, bool LDSMSG>
+static hipError_t generic_launch_k(const qbp::GenericParams& G, int grid, int threads, size_t lds, hipStream_t s)
+{
+    auto kern = qbp::bp_generic_kernel<VARIANT, MC, LDSMSG>;
+    static thread_local size_t lds_set[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || lds_set[dev] < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) lds_set[dev] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, G);
+    return hipGetLastError();
+}
+
+template <bool MC, bool LDSMSG>
+static hipError_t generic_launch_v(int variant, const qbp::GenericParams& G, int grid, int threads, size_t lds,
+                                   hipStream_t s)
+{
+    switch (variant) {
+        case QBP_SUM_PRODUCT: return generic_launch_k<0, MC, LDSMSG>(G, grid, threads, lds, s);
+        case QBP_DAMPED_SP:   return generic_launch_k<1, MC, LDSMSG>(G, grid, threads, lds, s);
+        default:              return generic_launch_k<2, MC, LDSMSG>(G, grid, threads, lds, s);
+    }
+}
+
+// Launch geometry of the general-H kernel (one workgroup per syndrome at a time):
+//   messages in LDS when they fit (16 E bytes + bookkeeping <= 160 KiB), else in a global workspace;
+//   threads per workgroup: the checks of weight <= 8 in as few, as full passes as possible
+//   (864 checks: 896 threads, one pass; 2592: 896 threads, three passes), at most 1024;
+//   workgroups per CU: as many as fit 16 wavefronts (the kernel's 128-register budget) and the LDS.
+struct GenericGeom { bool lds_msgs; int threads, per_cu, grid; size_t lds; };
+
+static GenericGeom generic_geometry(const qbp_handle* h, long long B)
+{
+    GenericGeom g{};
+    const size_t lds_full = qbp::generic_lds_bytes(h->m, std::max(h->E, 1), true);
+    g.lds_msgs = lds_full <= (size_t)160 * 1024;
+    g.lds = g.lds_msgs ? lds_full : qbp::generic_lds_bytes(h->m, std::max(h->E, 1), false);
+    const int short_rows = std::max(1, h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 1] - h->row_off[1]);
+    const int work = std::max(short_rows, 64);
+    const int passes = (work + 1023) / 1024;
+    int threads = (((work + passes - 1) / passes) + 63) / 64 * 64;
+    int per_cu = std::max(1, 1024 / threads);
+    if (g.lds) per_cu = (int)std::min<size_t>((size_t)per_cu, std::max<size_t>(1, ((size_t)160 * 1024) / g.lds));
+    per_cu = std::min(per_cu, 8);
+    // batches that cannot fill the chip: one wide workgroup per syndrome (latency of a single decode)
+    if (B < (long long)h->num_cu * per_cu) {
+        per_cu = 1;
+        const int wide = std::max(std::max(short_rows, h->n / 2), 64);
+        threads = std::min(1024, (wide + 63) / 64 * 64);
+    }
+    if (h->opt_threads > 0) threads = std::min(1024, (h->opt_threads + 63) / 64 * 64);
+    if (h->opt_blocks_per_cu > 0) per_cu = h->opt_blocks_per_cu;
+    g.threads = threads; g.per_cu = per_cu;
+    g.grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * per_cu));
+    return g;
+}
+
+static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior, int64_t B,
+                          int max_iter, int variant, double alpha, double damping, double clip_llr,
+                          unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
+                          double* d_llr, double* d_dump, int dump_iter, double dump_div, hipStream_t s,
+                          const qbp::GenericParams* mc = nullptr)
+{
+    if ((flags & QBP_FLAG_PAIRWISE_COLSUM) && h->max_col_deg > qbp::GENERIC_PAIRWISE_MAX_COL)
+        return fail(QBP_E_UNSUPPORTED, "QBP_FLAG_PAIRWISE_COLSUM supports column weights up to %d (got %d)",
+                    qbp::GENERIC_PAIRWISE_MAX_COL, h->max_col_deg);
+    const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
+    const GenericGeom g = generic_geometry(h, B);
+    if (g.lds > (size_t)160 * 1024)
+        return fail(QBP_E_UNSUPPORTED, "m = %d checks need %zu B of LDS for the parity bits (limit 160 KiB)",
+                    h->m, g.lds);
+    if (!g.lds_msgs) {
+        HIP_TRY(h->d_wsQ.reserve((size_t)g.grid * E));
+        HIP_TRY(h->d_wsR.reserve((size_t)g.grid * E));
+    }
+    HIP_TRY(h->d_prior_sorted.reserve(n));
+    hipLaunchKernelGGL(qbp::generic_permute_prior, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_prior,
+                       h->d_svar.p, h->d_prior_sorted.p, (int)n);
+    HIP_TRY(hipGetLastError());
+    qbp::GenericParams G{};
+    G.m = h->m; G.n = h->n; G.E = h->E;
+    G.srow = h->d_srow.p; G.srow_e0 = h->d_srow_e0.p; G.srow_deg = h->d_srow_deg.p;
+    G.col_idx = h->d_col_idx.p; G.epos = h->d_epos.p;
+    G.long_edge_row = h->d_long_edge_row.p;
+    {
+        const size_t n_long = (size_t)(h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 2] - h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 1]);
+        HIP_TRY(h->d_wsL.reserve((size_t)g.grid * 3 * std::max<size_t>(n_long, 1)));
+        G.wsL = h->d_wsL.p;
+    }
+    std::copy(std::begin(h->row_off), std::end(h->row_off), G.row_off);
+    std::copy(std::begin(h->row_base), std::end(h->row_base), G.row_base);
+    G.svar = h->d_svar.p; G.vpos = h->d_vpos.p; G.vrow = h->d_vrow.p; G.lcol_ptr = h->d_lcol_ptr.p;
+    std::copy(std::begin(h->col_off), std::end(h->col_off), G.col_off);
+    std::copy(std::begin(h->gcol_base), std::end(h->gcol_base), G.col_base);
+    G.prior_sorted = h->d_prior_sorted.p;
+    G.syndromes = d_syndromes; G.B = B; G.max_iter = max_iter; G.flags = flags;
+    G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
+    G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
+    G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p;
+    G.dump_R = d_dump; G.dump_iter = dump_iter; G.dump_div = dump_div;
+    h->last_threads = g.threads; h->last_lds = (int)g.lds; h->last_grid = g.grid;
+    if (mc) {
+        // Monte-Carlo mode: per-workgroup scratch for the sampled error
+        HIP_TRY(h->d_wsE.reserve((size_t)g.grid * ((n + 3) / 4) * 4));
+        G.lx_cols = mc->lx_cols; G.trial_begin = mc->trial_begin; G.seed = mc->seed;
+        G.threshold = mc->threshold; G.draws = mc->draws; G.half_distance = mc->half_distance;
+        G.counters = mc->counters; G.wsE = h->d_wsE.p;
+        G.fail_list = mc->fail_list; G.fail_count = mc->fail_count; G.fail_syn = mc->fail_syn;
+        G.fail_llr = mc->fail_llr; G.fail_hard = mc->fail_hard; G.fail_err = mc->fail_err;
+        HIP_TRY(g.lds_msgs ? (generic_launch_v<true, true>(variant, G, g.grid, g.threads, g.lds, s))
+                           : (generic_launch_v<true, false>(variant, G, g.grid, g.threads, g.lds, s)));
+        return QBP_OK;
+    }
+    HIP_TRY(g.lds_msgs ? (generic_launch_v<false, true>(variant, G, g.grid, g.threads, g.lds, s))
+                       : (generic_launch_v<false, false>(variant, G, g.grid, g.threads, g.lds, s)));
+    return QBP_OK;
+}
+
 extern "C" {
 
 const char* qbp_last_error(void) { return g_err; }
@@ -450,6 +610,10 @@ try {
     up(h->d_epos, T.epos);
     up(h->d_cpos, T.cpos);
     up(h->d_long_edge_row, T.long_edge_row);
+    up(h->d_vpos, T.vpos);
+    up(h->d_vrow, T.vrow);
+    up(h->d_lcol_ptr, T.lcol_ptr);
+    std::copy(std::begin(T.gcol_base), std::end(T.gcol_base), h->gcol_base);
     std::copy(std::begin(T.row_base), std::end(T.row_base), h->row_base);
     up(h->d_srow, T.srow);
     up(h->d_srow_e0, T.srow_e0);
@@ -538,79 +702,11 @@ void qbp_destroy(qbp_handle* h)
     h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release(); h->d_wsE.release(); h->d_svar.release(); h->d_sedge.release();
     h->d_srow.release(); h->d_srow_e0.release(); h->d_srow_deg.release();
     h->d_epos.release(); h->d_cpos.release(); h->d_long_edge_row.release(); h->d_wsL.release();
+    h->d_vpos.release(); h->d_vrow.release(); h->d_lcol_ptr.release(); h->d_prior_sorted.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
     delete h;
-}
-
-static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior, int64_t B,
-                          int max_iter, int variant, double alpha, double damping, double clip_llr,
-                          unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
-                          double* d_llr, double* d_dump, int dump_iter, double dump_div, hipStream_t s,
-                          const qbp::GenericParams* mc = nullptr)
-{
-    // general-H kernel: one workgroup per syndrome, messages in a global workspace.  Batches that
-    // cannot fill the chip with 256-thread workgroups get wider ones (latency of a single decode
-    // of a large matrix: checks / variables per thread shrink 4x).
-    // Workgroup shape: 256 threads, 4 workgroups per CU.  Wider (up to 1024 threads, one per CU)
-    // when the batch cannot fill the chip anyway (single decodes of large matrices: the checks /
-    // variables per thread shrink 4x) and when one syndrome's messages exceed 256 KB: then four
-    // workspaces per CU overflow the 256 MiB Infinity Cache and more threads per syndrome is the
-    // way to more loads in flight (2592 x 7776 space-time matrix, 400 KB: 1.2e5 syndromes/s with
-    // 1024 threads against 8.5e4 with 4 x 256; [[288,12,18]], 14 KB: 1.3e6 against 2.5e6).
-    const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
-    const bool wide = B < (long long)h->num_cu * 2 || 2 * E * 8 + n * 9 >= 256 * 1024;
-    const int threads = wide ? std::min(1024, std::max(256, (std::max(h->m, 64) + 63) / 64 * 64)) : 256;
-    int per_cu = wide ? 1 : 4;
-    if (h->opt_blocks_per_cu > 0) per_cu = h->opt_blocks_per_cu;
-    else while (per_cu > 2 && (double)h->num_cu * per_cu * (double)(2 * E * 8 + n * 9) > 256e6) --per_cu;
-    const int grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * per_cu));
-    HIP_TRY(h->d_wsQ.reserve((size_t)grid * E));
-    HIP_TRY(h->d_wsR.reserve((size_t)grid * E));
-    HIP_TRY(h->d_wsV.reserve((size_t)grid * n));
-    HIP_TRY(h->d_wsC.reserve((size_t)grid * n));
-    qbp::GenericParams G{};
-    G.m = h->m; G.n = h->n; G.E = h->E;
-    G.col_idx = h->d_col_idx.p; G.col_ptr = h->d_col_ptr.p;
-    G.srow = h->d_srow.p; G.srow_e0 = h->d_srow_e0.p; G.srow_deg = h->d_srow_deg.p;
-    G.epos = h->d_epos.p; G.cpos = h->d_cpos.p;
-    G.long_edge_row = h->d_long_edge_row.p;
-    {
-        const size_t n_long = (size_t)(h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 2] - h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 1]);
-        HIP_TRY(h->d_wsL.reserve((size_t)grid * 3 * std::max<size_t>(n_long, 1)));
-        G.wsL = h->d_wsL.p;
-    }
-    std::copy(std::begin(h->row_off), std::end(h->row_off), G.row_off);
-    std::copy(std::begin(h->row_base), std::end(h->row_base), G.row_base);
-    G.syndromes = d_syndromes; G.prior = d_prior; G.B = B; G.max_iter = max_iter; G.flags = flags;
-    G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
-    G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
-    G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p; G.wsV = h->d_wsV.p; G.wsC = h->d_wsC.p;
-    G.dump_R = d_dump; G.dump_iter = dump_iter; G.dump_div = dump_div;
-    h->last_threads = threads; h->last_lds = 0; h->last_grid = grid;
-    if (mc) {
-        // Monte-Carlo mode: per-workgroup error / syndrome scratch
-        HIP_TRY(h->d_wsE.reserve((size_t)grid * ((n + 3) / 4) * 4));
-        HIP_TRY(h->d_wsS.reserve((size_t)grid * (size_t)h->m));
-        G.lx_cols = mc->lx_cols; G.trial_begin = mc->trial_begin; G.seed = mc->seed;
-        G.threshold = mc->threshold; G.draws = mc->draws; G.half_distance = mc->half_distance;
-        G.counters = mc->counters; G.wsE = h->d_wsE.p; G.wsS = h->d_wsS.p;
-        switch (variant) {
-            case QBP_SUM_PRODUCT: hipLaunchKernelGGL((qbp::bp_generic_kernel<0, true>), dim3(grid), dim3(threads), 0, s, G); break;
-            case QBP_DAMPED_SP:   hipLaunchKernelGGL((qbp::bp_generic_kernel<1, true>), dim3(grid), dim3(threads), 0, s, G); break;
-            default:              hipLaunchKernelGGL((qbp::bp_generic_kernel<2, true>), dim3(grid), dim3(threads), 0, s, G); break;
-        }
-        HIP_TRY(hipGetLastError());
-        return QBP_OK;
-    }
-    switch (variant) {
-        case QBP_SUM_PRODUCT: hipLaunchKernelGGL((qbp::bp_generic_kernel<0>), dim3(grid), dim3(threads), 0, s, G); break;
-        case QBP_DAMPED_SP:   hipLaunchKernelGGL((qbp::bp_generic_kernel<1>), dim3(grid), dim3(threads), 0, s, G); break;
-        default:              hipLaunchKernelGGL((qbp::bp_generic_kernel<2>), dim3(grid), dim3(threads), 0, s, G); break;
-    }
-    HIP_TRY(hipGetLastError());
-    return QBP_OK;
 }
 
 static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior, int64_t B,
@@ -680,6 +776,9 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     if (h->opt_force_generic) kernel = 2;
     if (kernel == 1 && !h->fused_ok) return fail(QBP_E_UNSUPPORTED, "H does not fit the on-chip kernel");
     if (kernel == 0) kernel = h->fused_ok ? 1 : ((B >= 131072 && h->E <= 2048) ? 3 : 2);
+    // numpy's pairwise column sums only differ from 8 entries per column on; those matrices never
+    // fit the on-chip kernel, and only the general-H kernel implements that order
+    if ((flags & QBP_FLAG_PAIRWISE_COLSUM) && h->max_col_deg >= 8) kernel = 2;
     h->last_kernel = kernel;
     if (kernel == 3)
         return stream_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr, flags,
@@ -786,7 +885,12 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
 {
     int rc = check_decode_args(h, B, iteration + 1, variant);
     if (rc) return rc;
-    if (variant == QBP_SUM_PRODUCT) variant = QBP_DAMPED_SP;   // same update with alpha=damping=1
+    if (variant == QBP_SUM_PRODUCT) {
+        // plain sum-product = the damped update with alpha = damping = 1 and no LLR clip: the
+        // caller's alpha / damping / clip_llr are ignored, as QBP_SUM_PRODUCT ignores them everywhere
+        variant = QBP_DAMPED_SP;
+        alpha = 1.0; damping = 1.0; clip_llr = __builtin_inf();
+    }
     if (B == 0) return QBP_OK;
     if (!syndromes || !prior || !messages) return fail(QBP_E_INVALID, "null pointer");
     DeviceScope on_device(h->device);
@@ -1018,8 +1122,10 @@ try {
     HIP_TRY(h->d_hard.reserve((size_t)T * n));
     HIP_TRY(h->d_prior.reserve(n));
     HIP_TRY(h->d_counters.reserve(qbp::NUM_COUNTERS));
-    std::vector<double> prior(n, 1.0);
-    HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+    {
+        const std::vector<double> prior(n, 1.0);        // a local: copied synchronously
+        HIP_TRY(hipMemcpy(h->d_prior.p, prior.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, qbp::NUM_COUNTERS * sizeof(long long), s));
     LaunchCfg cfg;
     rc = make_cfg(h, T, &cfg);
@@ -1054,6 +1160,9 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_KERNEL:
             if (value < 0 || value > 3) return fail(QBP_E_INVALID, "kernel selector out of range");
             h->opt_kernel = (int)value; return QBP_OK;
+        case QBP_OPT_GENERAL_THREADS:
+            if (value < 0 || value > 1024) return fail(QBP_E_INVALID, "threads per workgroup out of range");
+            h->opt_threads = (int)value; return QBP_OK;
         default: return fail(QBP_E_INVALID, "unknown option %d", option);
     }
 }

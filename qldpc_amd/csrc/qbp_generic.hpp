@@ -1,11 +1,28 @@
 // General-H belief propagation: any parity-check matrix (irregular degrees, wide rows, large m/n:
-// space-time and circuit-level matrices).  One workgroup per
-// syndrome (256 threads when there are enough syndromes to fill the chip, up to 1024 for the
-// one-syndrome-per-call users of large matrices); messages live in a per-workgroup global-memory
-// workspace (L2-resident for the sizes of interest) instead of registers/LDS.  Threads take checks
-// in the check step (by weight class: coalesced, straight-line) and variables in the variable step;
-// every product / sum runs sequentially in the reference's order (ascending column within a row: np.prod(axis=1); ascending check within a column: np.sum(axis=0)), so the
-// arithmetic is the same as the fused kernel's and the oracle's.
+// space-time and circuit-level matrices).
+//
+// One workgroup per syndrome.  The 2E messages of the syndrome live
+//   * in LDS when 16 E bytes (plus the small bookkeeping below) fit the CU's 160 KiB   (LDSMSG), or
+//   * in a per-workgroup global workspace that stays in L2 / Infinity Cache.
+// One BP iteration is TWO workgroup barriers:
+//   check step     one thread per check; checks are sorted by weight and the work items of all
+//                  weight classes form ONE index range (a wave straddling two classes diverges, all
+//                  others run one straight-line body): D coalesced loads, the check update, D
+//                  coalesced stores ("class-blocked, transposed" layout, see GenericParams);
+//   -- barrier A --
+//   variable step  one thread per variable, variables sorted by column weight in the same way:
+//                  gathers the column's messages (ascending check: np.sum(R, axis=0)), posterior
+//                  value, new variable->check messages in place.  The syndrome test of the reference
+//                  (H hard == s, beliefPropagation.py:137-139) is kept incrementally: every variable
+//                  whose hard decision is 1 flips the parity bit of its checks in an LDS bit vector
+//                  that started as the syndrome, and moves a counter of unsatisfied checks;
+//   -- barrier B --
+//   the counter is zero <=> converged.
+// Posterior values and hard decisions are not stored per iteration: when a syndrome is emitted
+// (first convergence, or the iteration limit) they are recomputed from R, which is still that
+// iteration's.  Every product / sum runs sequentially in the reference's order (ascending column
+// within a row: np.prod(axis=1); ascending check within a column), so the outputs are bit-identical
+// to the on-chip kernel's and the streaming kernel's (tested).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,51 +34,61 @@
 namespace qbp {
 
 constexpr int GENERIC_MAX_ROW_CLASS = 8;   // rows of weight 1 .. 8 have their own instantiation
+constexpr int GENERIC_MAX_COL_CLASS = 4;   // columns of weight 1 .. 4 likewise
+constexpr int GENERIC_PAIRWISE_LEVELS = 4; // numpy's pairwise sum recursion, unrolled this deep
+constexpr int GENERIC_PAIRWISE_MAX_COL = 128 << GENERIC_PAIRWISE_LEVELS;
 
 struct GenericParams {
     int m, n, E;
-    const int32_t* col_idx;     // CSR column indices
-    const int32_t* col_ptr;     // CSC
-    // Message layout of one syndrome ("class-blocked, transposed"): checks are sorted by row weight
-    // (stable; build_tables in qbp.hip); the cnt checks of weight D occupy one block in which entry
-    // j of the i-th such check sits at row_base[D] + j * cnt + i, so that consecutive threads (one
-    // check each) touch consecutive doubles.  Checks of weight > 8 keep their entries contiguous,
-    // behind the blocks: positions [row_base[9], E) = the "long" edges; their transcendental work is
-    // done one thread per EDGE (long_edge_row = index of the check among the long ones), only the
-    // sequential row product / minimum search runs one thread per check.
-    const int32_t* srow;        // [m] check index, sorted by weight class
+    // ---- checks, sorted by row weight (stable): sorted position w -> check srow[w] ------------
+    // Message layout of one syndrome ("class-blocked, transposed"): the cnt checks of weight D
+    // occupy one block in which entry j of the i-th such check sits at row_base[D] + j * cnt + i,
+    // so that consecutive threads (one check each) touch consecutive doubles.  Checks of weight > 8
+    // keep their entries contiguous behind the blocks: positions [row_base[9], E) = the "long"
+    // edges; their transcendental work is done one thread per EDGE (long_edge_row = index of the
+    // check among the long ones), only the sequential row product / minimum search per check.
+    const int32_t* srow;        // [m] check index
     const int32_t* srow_e0;     // [m] first CSR edge of that check
     const int32_t* srow_deg;    // [m] its weight
+    const int32_t* col_idx;     // CSR column indices (Monte-Carlo: syndrome of the sampled error)
     const int32_t* epos;        // [E] CSR edge -> position in the layout
-    const int32_t* cpos;        // [E] CSC slot (column-major, ascending check) -> position
-    int row_off[GENERIC_MAX_ROW_CLASS + 3];    // class boundaries in srow (0 .. 8, > 8)
+    int row_off[GENERIC_MAX_ROW_CLASS + 3];    // class boundaries in srow (weights 0 .. 8, > 8)
     int row_base[GENERIC_MAX_ROW_CLASS + 2];   // first position of each class block
     const int32_t* long_edge_row;   // [E - row_base[9]]
     double* wsL;                // [grid][3 * number of long checks] row product / (sprod, min1, min2)
+    // ---- variables, sorted by column weight (stable): sorted position x -> variable svar[x] ----
+    // vpos / vrow hold, per column entry, the message position and the SORTED position of the
+    // entry's check, in the same blocked-transposed arrangement: entry j (ascending check) of the
+    // i-th variable of weight D at col_base[D] + j * cnt + i; variables of weight > 4 keep their
+    // entries contiguous from lcol_ptr[i] on.
+    const int32_t* svar;        // [n]
+    const int32_t* vpos;        // [E]
+    const int32_t* vrow;        // [E]
+    const int32_t* lcol_ptr;    // [number of long columns + 1], absolute offsets into vpos / vrow
+    int col_off[GENERIC_MAX_COL_CLASS + 3];    // class boundaries in svar (weights 0 .. 4, > 4)
+    int col_base[GENERIC_MAX_COL_CLASS + 2];
+    const double* prior_sorted; // [n] prior of the sorted variable x (permuted once per call)
+    // ---- the call ---------------------------------------------------------------------------------
     const uint8_t* syndromes;
-    const double* prior;
     long long B;
     int max_iter;
-    unsigned flags;
+    unsigned flags;             // QBP_FLAG_*: bit 0 force full, bit 2 numpy pairwise column sums
     double alpha, damping, clip_llr;
     uint8_t* hard;
     uint8_t* converged;
     int32_t* iters;
     double* llr;
-    // workspace, one slice per workgroup
-    double* wsQ;                // [grid][E]
+    double* wsQ;                // [grid][E]   (messages in global memory only)
     double* wsR;                // [grid][E]
-    double* wsV;                // [grid][n]
-    uint8_t* wsC;               // [grid][n] candidate error
     // message dump (alpha_estimation=True of rework/decoding.py:58-59 and :168-169): after the check
     // step of iteration dump_iter, write the check->variable messages of every edge (CSR order)
-    // to dump_R[b][E] and stop decoding that syndrome.  dump_scale divides (min-sum: 1/alpha).
+    // to dump_R[b][E] and stop decoding that syndrome.  dump_div divides (min-sum: alpha).
     double* dump_R;
     int dump_iter;
     double dump_div;
-    // Monte-Carlo mode (MC instantiation; paperResults_GPU.py:95-151 for any H): B trials starting
-    // at global index trial_begin; errors from the counter-based sampler, syndrome = H e, decode,
-    // classify against the logical operators, add to counters[NUM_COUNTERS]
+    // ---- Monte-Carlo mode (MC instantiation; paperResults_GPU.py:95-151 for any H): B trials
+    // starting at global index trial_begin; errors from the counter-based sampler, syndrome = H e,
+    // decode, classify against the logical operators, add to counters[NUM_COUNTERS]
     const unsigned long long* lx_cols;  // [n] bit l = Lx[l][v]
     long long trial_begin;
     unsigned long long seed;
@@ -70,8 +97,23 @@ struct GenericParams {
     int half_distance;
     long long* counters;
     uint8_t* wsE;                       // [grid][n4] sampled error of the current trial
-    uint8_t* wsS;                       // [grid][m] its syndrome
+    // Monte-Carlo + OSD: records of the trials BP did not converge on, indexed by the trial's
+    // position in this launch (same convention as the on-chip kernel, qbp_kernels.hpp)
+    long long* fail_list;               // null = classify the BP output directly
+    unsigned long long* fail_count;
+    uint8_t* fail_syn;                  // [B][m]
+    double* fail_llr;                   // [B][n]
+    uint8_t* fail_hard;                 // [B][n]
+    uint8_t* fail_err;                  // [B][n]
 };
+
+// Dynamic LDS of one workgroup: messages (LDSMSG) + syndrome bits + two parity buffers + counters.
+__host__ __device__ inline size_t generic_lds_bytes(int m, int E, bool lds_msgs)
+{
+    const size_t mw = ((size_t)m + 31) >> 5;
+    const size_t words = ((3 * mw + 2 + 1) & ~(size_t)1) + 4 + NUM_COUNTERS;
+    return (lds_msgs ? (size_t)16 * (size_t)E : 0) + words * 4;
+}
 
 // Check update of one row held in registers: q[D] -> r[D]   (beliefPropagation.py:114-126 /
 // rework/decoding.py:28-56).  `scale` is false for the alpha_estimation dump of the damped variant
@@ -111,117 +153,285 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
         double prod = 1.0;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            t[j] = tanh_half(q[j]);
+            t[j] = tanh_half_msg<VARIANT>(q[j]);
             prod = (j == 0) ? t[0] : prod * t[j];
         }
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
             double po = div_nr(prod, ts);
-            po = sbit ? -po : po;
-            const double x = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+            po = __hiloint2double(__double2hiint(po) ^ (int)(sbit << 31), __double2loint(po));   // * sign
+            const double x = atanh2(clip_unit<VARIANT>(po));
             r[j] = (VARIANT == 1 && scale) ? x * alpha : x;
         }
     }
 }
 
-// __launch_bounds__(1024) = at most 128 registers: also right for the 256-thread launches, which
-// then fit 4 workgroups per CU (a 135-register build with 3 per CU was 30 % slower).
-template <int VARIANT, bool MC = false>
+// np.sum over the gathered column R[pos[0 .. n)] in numpy's pairwise order (the loop form of the
+// reference, decoding/beliefPropagation.py:68; oracle/bp_oracle.c:np_pairwise_sum states the
+// algorithm).  The recursion above 128 terms is unrolled LEVEL times (n <= 128 << LEVEL).
+template <int LEVEL>
+__device__ __forceinline__ double np_pairwise_gather(const double* R, const int32_t* pos, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = (i == 0) ? R[pos[0]] : res + R[pos[i]];
+        return res;
+    }
+    if (LEVEL == 0 || n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = R[pos[j]];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += R[pos[i + j]];
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += R[pos[i]];
+        return res;
+    }
+    if constexpr (LEVEL > 0) {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_gather<LEVEL - 1>(R, pos, n2) + np_pairwise_gather<LEVEL - 1>(R, pos + n2, n - n2);
+    }
+    return 0.0;
+}
+
+// Once per decode call: prior of the sorted variable x.
+__global__ void generic_permute_prior(const double* prior, const int32_t* svar, double* out, int n)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n) out[x] = prior[svar[x]];
+}
+
+// __launch_bounds__(1024) = at most 128 registers: also right for the smaller launches, which then
+// fit several workgroups per CU.
+template <int VARIANT, bool MC, bool LDSMSG>
 __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
+    extern __shared__ double gsm[];
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63;
     const int m = P.m, n = P.n, E = P.E;
-    constexpr int RC = GENERIC_MAX_ROW_CLASS;
-    double* Q = P.wsQ + (size_t)blockIdx.x * E;
-    double* R = P.wsR + (size_t)blockIdx.x * E;
-    double* V = P.wsV + (size_t)blockIdx.x * n;
-    uint8_t* cand = P.wsC + (size_t)blockIdx.x * n;
+    constexpr int RC = GENERIC_MAX_ROW_CLASS, CC = GENERIC_MAX_COL_CLASS;
+    double* Q;
+    double* R;
+    unsigned* words;
+    if constexpr (LDSMSG) {
+        Q = gsm; R = gsm + E; words = reinterpret_cast<unsigned*>(gsm + 2 * (size_t)E);
+    } else {
+        Q = P.wsQ + (size_t)blockIdx.x * E; R = P.wsR + (size_t)blockIdx.x * E;
+        words = reinterpret_cast<unsigned*>(gsm);
+    }
+    const int mw = (m + 31) >> 5;
+    unsigned* const synw = words;                   // [mw] syndrome bits, sorted check order
+    unsigned* const par = words + mw;               // [2][mw] parity of H hard ^ s, by iteration parity
+    int* const unsat = reinterpret_cast<int*>(words + 3 * mw);     // [2] number of set bits of par
+    const int acc_off = (3 * mw + 2 + 1) & ~1;
+    unsigned long long* const mc_lmask = reinterpret_cast<unsigned long long*>(words + acc_off);
+    int* const mc_weight = reinterpret_cast<int*>(words + acc_off + 2);
+    int* const mc_diff = mc_weight + 1;
+    int* const mc_cnt = mc_diff + 1;                // [NUM_COUNTERS] this workgroup's counter row (MC)
+
     const bool force_full = (P.flags & 1u) != 0;
+    const bool pairwise = (P.flags & 4u) != 0;
     const double one_minus_damping = 1.0 - P.damping;
-    // Monte-Carlo mode: workgroup-wide accumulators of the trial being classified, and thread 0's
-    // counter row for all trials of this workgroup
-    __shared__ unsigned long long mc_lmask;
-    __shared__ int mc_weight, mc_diff;
-    int mc_cnt[NUM_COUNTERS] = {0};
     const int n4 = (n + 3) / 4;
     uint8_t* const err = MC ? P.wsE + (size_t)blockIdx.x * n4 * 4 : nullptr;
     if constexpr (MC) {
-        if (tid == 0) { mc_lmask = 0ull; mc_weight = 0; mc_diff = 0; }
+        if (tid == 0) {
+            *mc_lmask = 0ull; *mc_weight = 0; *mc_diff = 0;
+            for (int i = 0; i < NUM_COUNTERS; ++i) mc_cnt[i] = 0;
+        }
     }
+    const int first_long = P.row_off[RC + 1], n_long = P.row_off[RC + 2] - first_long;
+    const int lbase = P.row_base[RC + 1], n_ledges = E - lbase;
+    const int first_lcol = P.col_off[CC + 1], n_lcol = P.col_off[CC + 2] - first_lcol;
+
+    // new variable->check message of one edge (:133 / rework/decoding.py:65-66, :179-181)
+    auto q_update = [&](int o, double val, double r) {
+        const double qn = val - r;
+        if constexpr (VARIANT == 0) {
+            Q[o] = qn;
+        } else {
+            const double q = P.damping * qn + one_minus_damping * Q[o];
+            const double y = q < -P.clip_llr ? -P.clip_llr : q;     // np.clip, NaN stays NaN
+            Q[o] = y > P.clip_llr ? P.clip_llr : y;
+        }
+    };
 
     for (long long b = blockIdx.x; b < P.B; b += gridDim.x) {
-        const uint8_t* syn = P.syndromes + b * m;
+        const uint8_t* const syn = MC ? nullptr : P.syndromes + b * m;
+        if (tid == 0) unsat[0] = 0;
         if constexpr (MC) {
-            // errors of trial trial_begin + b (one Philox evaluation per four qubits), then its
-            // syndrome H e mod 2 (beliefPropagationGPU.py:195-198)
-            uint8_t* const sy = P.wsS + (size_t)blockIdx.x * m;
+            // errors of trial trial_begin + b: one Philox evaluation per four qubits
+            // (beliefPropagationGPU.py:195)
             for (int g = tid; g < n4; g += nt)
                 reinterpret_cast<unsigned*>(err)[g] =
                     mc_error_quad((unsigned long long)(P.trial_begin + b), g, P.draws, P.seed, P.threshold);
-            __syncthreads();
-            for (int i = tid; i < m; i += nt) {
-                unsigned par = 0;
-                const int e0 = P.srow_e0[i], deg = P.srow_deg[i];
-                for (int j = 0; j < deg; ++j) par ^= err[P.col_idx[e0 + j]];
-                sy[P.srow[i]] = (uint8_t)(par & 1u);
-            }
-            syn = sy;
-            __syncthreads();
         }
-        for (int e = tid; e < E; e += nt) Q[P.epos[e]] = P.prior[P.col_idx[e]];   // Q = prior on edges
+        __syncthreads();      // (also: the previous syndrome's last readers of LDS are done)
+        // ---- syndrome bits in sorted check order; parity buffer 0 := syndrome -------------------
+        {
+            int cnt = 0;
+            for (int w0 = tid - lane; w0 < m; w0 += nt) {           // w0 is wave-uniform
+                const int w = w0 + lane;
+                unsigned bit = 0;
+                if (w < m) {
+                    if constexpr (MC) {                             // syndrome = H e mod 2 (:198)
+                        const int e0 = P.srow_e0[w], deg = P.srow_deg[w];
+                        for (int j = 0; j < deg; ++j) bit ^= err[P.col_idx[e0 + j]];
+                        bit &= 1u;
+                    } else {
+                        bit = syn[P.srow[w]] & 1u;
+                    }
+                }
+                const unsigned long long mask = __ballot(bit != 0);
+                if (lane == 0) {
+                    const int wi = w0 >> 5;
+                    synw[wi] = (unsigned)mask; par[wi] = (unsigned)mask;
+                    if (wi + 1 < mw) { synw[wi + 1] = (unsigned)(mask >> 32); par[wi + 1] = (unsigned)(mask >> 32); }
+                    cnt += __builtin_popcountll(mask);
+                }
+            }
+            if (lane == 0 && cnt) atomicAdd(&unsat[0], cnt);
+        }
+        // ---- Q = prior on the edges (beliefPropagation.py:107) -------------------------------------
+        for (int x = tid + P.col_off[1]; x < first_lcol; x += nt) {
+            const int D = 1 + (x >= P.col_off[2]) + (x >= P.col_off[3]) + (x >= P.col_off[4]);
+            const int cnt = P.col_off[D + 1] - P.col_off[D];
+            const int32_t* const pos = P.vpos + P.col_base[D] + (x - P.col_off[D]);
+            const double pv = P.prior_sorted[x];
+            for (int j = 0; j < D; ++j) Q[pos[(size_t)j * cnt]] = pv;
+        }
+        for (int i = tid; i < n_lcol; i += nt) {
+            const double pv = P.prior_sorted[first_lcol + i];
+            for (int k = P.lcol_ptr[i]; k < P.lcol_ptr[i + 1]; ++k) Q[P.vpos[k]] = pv;
+        }
         __syncthreads();
-        bool frozen = false;
-        int it = 0;
-        // Monte-Carlo: classification of the candidate error in `cand` (paperResults_GPU.py:113-144),
-        // called by the whole workgroup right after the barrier that made `cand` final
-        auto classify = [&](int conv, int it_done) {
+        const int syn_weight = unsat[0];      // unsatisfied checks of the all-zero candidate
+
+        // Posterior value of a long column (weight > 4) from the current R
+        auto long_column_value = [&](int i, const int32_t*& pos, int& deg) {
+            const int k0 = P.lcol_ptr[i];
+            deg = P.lcol_ptr[i + 1] - k0;
+            pos = P.vpos + k0;
+            double s = 0.0;
+            if (pairwise && deg >= 8) {
+                s = np_pairwise_gather<GENERIC_PAIRWISE_LEVELS>(R, pos, deg);
+            } else {
+                for (int j = 0; j < deg; ++j) {
+                    const double r = R[pos[j]];
+                    s = (j == 0) ? r : s + r;                     // ascending check order
+                }
+            }
+            return s + P.prior_sorted[first_lcol + i];
+        };
+
+        // Outputs of this syndrome from the current R (values, hard decisions): decode mode writes
+        // them, Monte-Carlo mode classifies them (paperResults_GPU.py:113-144) or leaves the trial
+        // to OSD-0.  Called by the whole workgroup.
+        auto emit = [&](int conv, int it_done) {
+            const bool to_osd = MC && P.fail_list != nullptr && !conv;
             unsigned long long lm = 0ull;
             int ew = 0, df = 0;
-            for (int v = tid; v < n; v += nt) {
-                const unsigned e = err[v];
-                const unsigned res = (unsigned)cand[v] ^ e;
-                ew += (int)e;
-                df |= (int)res;
-                if (res) lm ^= P.lx_cols[v];
+            for (int x = tid; x < n; x += nt) {
+                double val;
+                if (x < P.col_off[1]) {
+                    val = P.prior_sorted[x];                        // isolated variable
+                } else if (x < first_lcol) {
+                    const int D = 1 + (x >= P.col_off[2]) + (x >= P.col_off[3]) + (x >= P.col_off[4]);
+                    const int cnt = P.col_off[D + 1] - P.col_off[D];
+                    const int32_t* const pos = P.vpos + P.col_base[D] + (x - P.col_off[D]);
+                    double s = 0.0;
+                    for (int j = 0; j < D; ++j) {
+                        const double r = R[pos[(size_t)j * cnt]];
+                        s = (j == 0) ? r : s + r;
+                    }
+                    val = s + P.prior_sorted[x];
+                } else {
+                    const int32_t* pos; int deg;
+                    val = long_column_value(x - first_lcol, pos, deg);
+                }
+                const int v = P.svar[x];
+                const unsigned hd = val < 0.0 ? 1u : 0u;
+                if constexpr (MC) {
+                    const unsigned e = err[v];
+                    if (to_osd) {
+                        P.fail_llr[b * n + v] = val;
+                        P.fail_hard[b * n + v] = (uint8_t)hd;
+                        P.fail_err[b * n + v] = (uint8_t)e;
+                    } else {
+                        const unsigned res = hd ^ e;
+                        ew += (int)e;
+                        df |= (int)res;
+                        if (res) lm ^= P.lx_cols[v];
+                    }
+                } else {
+                    if (P.llr) P.llr[b * n + v] = val;
+                    if (P.hard) P.hard[b * n + v] = (uint8_t)hd;
+                }
             }
-            if (lm) atomicXor(&mc_lmask, lm);
-            if (ew) atomicAdd(&mc_weight, ew);
-            if (df) atomicOr(&mc_diff, 1);
-            __syncthreads();
-            if (tid == 0) {
-                mc_count_trial(mc_cnt, mc_lmask, mc_weight, mc_diff, conv, it_done, P.half_distance);
-                mc_lmask = 0ull; mc_weight = 0; mc_diff = 0;
+            if constexpr (MC) {
+                if (to_osd) {
+                    for (int w = tid; w < m; w += nt)
+                        P.fail_syn[b * m + P.srow[w]] = (uint8_t)((synw[w >> 5] >> (w & 31)) & 1u);
+                    if (tid == 0) {
+                        P.fail_list[atomicAdd(P.fail_count, 1ull)] = b;
+                        mc_cnt[0] += 1; mc_cnt[6] += 1; mc_cnt[7] += it_done;   // BP bookkeeping only
+                    }
+                } else {
+                    if (lm) atomicXor(mc_lmask, lm);
+                    if (ew) atomicAdd(mc_weight, ew);
+                    if (df) atomicOr(mc_diff, 1);
+                    __syncthreads();
+                    if (tid == 0) {
+                        mc_count_trial(mc_cnt, *mc_lmask, *mc_weight, *mc_diff, conv, it_done, P.half_distance);
+                        *mc_lmask = 0ull; *mc_weight = 0; *mc_diff = 0;
+                    }
+                }
+            } else if (tid == 0) {
+                if (P.converged) P.converged[b] = (uint8_t)conv;
+                if (P.iters) P.iters[b] = it_done;
             }
         };
-        (void)classify;
-        for (; it < P.max_iter; ++it) {
+
+        bool frozen = false;
+        for (int it = 0; it < P.max_iter; ++it) {
             const bool scale = !(P.dump_R != nullptr && it == P.dump_iter);
-            // ---- check step, one thread per check, by weight class: D coalesced loads, straight-
-            //      line arithmetic, D coalesced stores
-#define QBP_ROW_CLASS(D)                                                                          \
-            {                                                                                     \
-                const int cnt = P.row_off[D + 1] - P.row_off[D];                                  \
-                for (int i = tid; i < cnt; i += nt) {                                             \
-                    const unsigned sbit = syn[P.srow[P.row_off[D] + i]] & 1u;                      \
-                    double q[D], r[D];                                                            \
-                    _Pragma("unroll") for (int j = 0; j < D; ++j) q[j] = Q[P.row_base[D] + j * cnt + i]; \
-                    generic_row_update<VARIANT, D>(q, r, sbit, P.alpha, scale);                   \
-                    _Pragma("unroll") for (int j = 0; j < D; ++j) R[P.row_base[D] + j * cnt + i] = r[j]; \
-                }                                                                                 \
-            }
-            QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
-            QBP_ROW_CLASS(5) QBP_ROW_CLASS(6) QBP_ROW_CLASS(7) QBP_ROW_CLASS(8)
+            // ================= check step =======================================================
+            for (int w_ = tid + P.row_off[1]; w_ < first_long; w_ += nt) {
+                // (opaque copy of the loop counter: keeps the per-class address arithmetic inside the
+                // loop.  Hoisted, it is ~60 loop-invariant registers that get spilled to scratch.)
+                int w = w_;
+                asm volatile("" : "+v"(w));
+                const int D = P.srow_deg[w];
+                const unsigned sbit = (synw[w >> 5] >> (w & 31)) & 1u;
+#define QBP_ROW_CLASS(DD)                                                                          \
+                case DD: {                                                                         \
+                    const int cnt = P.row_off[DD + 1] - P.row_off[DD];                             \
+                    const int base = P.row_base[DD] + (w - P.row_off[DD]);                         \
+                    double q[DD], r[DD];                                                           \
+                    _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = Q[base + j * cnt];       \
+                    generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale);                   \
+                    _Pragma("unroll") for (int j = 0; j < DD; ++j) R[base + j * cnt] = r[j];       \
+                } break;
+                switch (D) {
+                    QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
+                    QBP_ROW_CLASS(5) QBP_ROW_CLASS(6) QBP_ROW_CLASS(7) QBP_ROW_CLASS(8)
+                    default: break;
+                }
 #undef QBP_ROW_CLASS
+            }
             // ---- checks of weight > 8: the per-edge work (tanh; division + atanh) one thread per
             //      edge, the sequential part (np.prod in ascending column order / argmin and second
-            //      minimum) one thread per check, two workgroup barriers in between
-            const int first_long = P.row_off[RC + 1], n_long = P.row_off[RC + 2] - first_long;
+            //      minimum) one thread per check, two more workgroup barriers in between
             if (n_long > 0) {                                           // uniform
-                const int lbase = P.row_base[RC + 1], n_ledges = E - lbase;
                 double* const L = P.wsL + (size_t)blockIdx.x * 3 * n_long;
                 if constexpr (VARIANT != 2) {
-                    for (int k = tid; k < n_ledges; k += nt) R[lbase + k] = tanh_half(Q[lbase + k]);
+                    for (int k = tid; k < n_ledges; k += nt) R[lbase + k] = tanh_half_msg<VARIANT>(Q[lbase + k]);
                     __syncthreads();
                 }
                 for (int i = tid; i < n_long; i += nt) {
@@ -262,7 +472,8 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 __syncthreads();
                 for (int k = tid; k < n_ledges; k += nt) {
                     const int i = P.long_edge_row[k];
-                    const unsigned sbit = syn[P.srow[first_long + i]] & 1u;
+                    const int w = first_long + i;
+                    const unsigned sbit = (synw[w >> 5] >> (w & 31)) & 1u;
                     if constexpr (VARIANT == 2) {
                         const double x = Q[lbase + k];
                         const double sg = x < 0.0 ? -1.0 : 1.0;
@@ -274,83 +485,75 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
                         double po = div_nr(L[3 * i], ts);
                         po = sbit ? -po : po;
-                        const double x = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+                        const double x = atanh2(clip_unit<VARIANT>(po));
                         R[lbase + k] = (VARIANT == 1 && scale) ? x * P.alpha : x;
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads();                                          // ---- barrier A
             if (!scale) {
                 for (int e = tid; e < E; e += nt) P.dump_R[b * E + e] = R[P.epos[e]] / P.dump_div;
                 frozen = true;           // nothing else is reported for this syndrome
                 break;
             }
-            // ---- variable step (:129-136), one thread per variable: value, candidate error and
-            //      the new variable->check messages of its column
-            for (int v = tid; v < n; v += nt) {
-                double s = 0.0;
-                const int k0 = P.col_ptr[v], k1 = P.col_ptr[v + 1];
-                for (int k = k0; k < k1; ++k) {
-                    const double r = R[P.cpos[k]];
-                    s = (k == k0) ? r : s + r;                      // ascending check order
-                }
-                const double val = s + P.prior[v];
-                V[v] = val;
-                cand[v] = val < 0.0;
-                for (int k = k0; k < k1; ++k) {
-                    const int o = P.cpos[k];
-                    const double qn = val - R[o];
-                    if constexpr (VARIANT == 0) {
-                        Q[o] = qn;
-                    } else {
-                        const double q = P.damping * qn + one_minus_damping * Q[o];
-                        const double y = q < -P.clip_llr ? -P.clip_llr : q;     // np.clip, NaN stays NaN
-                        Q[o] = y > P.clip_llr ? P.clip_llr : y;
-                    }
-                }
+            // ================= variable step (:129-136) + incremental syndrome test (:137-139) ====
+            const int p = it & 1;
+            unsigned* const pbuf = par + p * mw;
+            {   // the other buffer becomes the syndrome again (its last readers passed barrier A)
+                unsigned* const obuf = par + (p ^ 1) * mw;
+                for (int i = tid; i < mw; i += nt) obuf[i] = synw[i];
+                if (tid == 0) unsat[p ^ 1] = syn_weight;
             }
-            __syncthreads();
-            // ---- syndrome check (:137-139) -----------------------------------------------------
-            int unsat = 0;
-            if (!frozen) {
-                for (int i = tid; i < m; i += nt) {
-                    unsigned par = syn[P.srow[i]] & 1u;
-                    const int e0 = P.srow_e0[i], deg = P.srow_deg[i];
-                    for (int j = 0; j < deg; ++j) par ^= cand[P.col_idx[e0 + j]];
-                    unsat |= (int)par;
+            int delta = 0;
+            auto flip = [&](int cw) {             // the check at sorted position cw changes parity
+                const unsigned bit = 1u << (cw & 31);
+                const unsigned old = atomicXor(&pbuf[cw >> 5], bit);
+                delta += (old & bit) ? -1 : 1;
+            };
+            for (int x_ = tid + P.col_off[1]; x_ < first_lcol; x_ += nt) {
+                int x = x_;
+                asm volatile("" : "+v"(x));
+                const int D = 1 + (x >= P.col_off[2]) + (x >= P.col_off[3]) + (x >= P.col_off[4]);
+#define QBP_COL_CLASS(DD)                                                                          \
+                case DD: {                                                                         \
+                    const int cnt = P.col_off[DD + 1] - P.col_off[DD];                             \
+                    const int base = P.col_base[DD] + (x - P.col_off[DD]);                         \
+                    int o[DD];                                                                     \
+                    double r[DD];                                                                  \
+                    _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = P.vpos[base + j * cnt];  \
+                    _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = R[o[j]];                 \
+                    double s = r[0];                                                               \
+                    _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];                   \
+                    const double val = s + P.prior_sorted[x];                                      \
+                    if (!frozen && val < 0.0) {                                                    \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(P.vrow[base + j * cnt]); \
+                    }                                                                              \
+                    _Pragma("unroll") for (int j = 0; j < DD; ++j) q_update(o[j], val, r[j]);      \
+                } break;
+                switch (D) {
+                    QBP_COL_CLASS(1) QBP_COL_CLASS(2) QBP_COL_CLASS(3) QBP_COL_CLASS(4)
+                    default: break;
                 }
+#undef QBP_COL_CLASS
             }
-            const int any_unsat = __syncthreads_or(unsat);   // also orders Q for the next check step
-            const bool conv = !frozen && !any_unsat;
-            if (conv) {
-                if constexpr (MC) {
-                    classify(1, it);
-                } else {
-                    for (int v = tid; v < n; v += nt) {
-                        if (P.llr) P.llr[b * n + v] = V[v];
-                        if (P.hard) P.hard[b * n + v] = cand[v];
-                    }
-                    if (tid == 0) {
-                        if (P.converged) P.converged[b] = 1;
-                        if (P.iters) P.iters[b] = it;
-                    }
+            for (int i = tid; i < n_lcol; i += nt) {
+                const int32_t* pos; int deg;
+                const double val = long_column_value(i, pos, deg);
+                if (!frozen && val < 0.0) {
+                    const int32_t* const row = P.vrow + (pos - P.vpos);
+                    for (int j = 0; j < deg; ++j) flip(row[j]);
                 }
+                for (int j = 0; j < deg; ++j) q_update(pos[j], val, R[pos[j]]);
+            }
+            if (delta) atomicAdd(&unsat[p], delta);
+            __syncthreads();                                          // ---- barrier B
+            if (frozen) continue;                                     // forced mode after convergence
+            const bool conv = unsat[p] == 0;                          // H hard == s
+            if (conv || it == P.max_iter - 1) {
+                emit(conv ? 1 : 0, it);
                 frozen = true;
-                if (!force_full) break;
-            }
-        }
-        if (!frozen) {
-            if constexpr (MC) {
-                classify(0, P.max_iter - 1);
-            } else {
-                for (int v = tid; v < n; v += nt) {
-                    if (P.llr) P.llr[b * n + v] = V[v];
-                    if (P.hard) P.hard[b * n + v] = cand[v];
-                }
-                if (tid == 0) {
-                    if (P.converged) P.converged[b] = 0;
-                    if (P.iters) P.iters[b] = P.max_iter - 1;
-                }
+                if (!(conv && force_full) || it == P.max_iter - 1) break;
+                __syncthreads();     // emission read R; the next check step overwrites it
             }
         }
         __syncthreads();

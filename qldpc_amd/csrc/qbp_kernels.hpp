@@ -124,7 +124,7 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
 //   [S]  next work index per slot
 //   [S]  MC logical-mask accumulator
 //   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
-//   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only), var_lds[DC][m], err_lds[S][n4] bytes (MC)
+//   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only), var_lds[DC][m], err_lds[2][S][n4] bytes (MC)
 template <int DC, int DV, int VARIANT, bool MC, bool FORCE_FULL, int MAX_THREADS, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kernel(const FusedParams P)
 {
@@ -154,10 +154,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     int* const active_count = words + 4 * S;
     int* const mc_count = words + 4 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
     int* const var_lds = words + 4 * S + 1 + S * NUM_COUNTERS;     // [DC][m], -1 = padding
-    // Monte-Carlo mode: sampled error bytes of the slot's current trial, [S][n4] (n4 = n rounded
-    // up to a multiple of 4), written by the slot's first ceil(n/4) lanes one barrier before use
-    const int n4 = (P.n_words4) * 4;
-    unsigned char* const err_lds = reinterpret_cast<unsigned char*>(var_lds + DC * m) + (size_t)sl * n4;
+    // Monte-Carlo mode: sampled error bytes of the slot's trials, [2][S][n4] (n4 = n rounded up to a
+    // multiple of 4), written by the slot's first ceil(n/4) lanes one barrier before use.  Two
+    // buffers per slot, used alternately by consecutive trials: the emission of a finished trial still
+    // reads the bytes of its isolated variables after barrier B2, while faster waves of the same slot
+    // may already be sampling the next trial at the top of the loop (no barrier in between).
+    unsigned err_par = 0;                         // buffer of the trial being decoded (uniform per slot)
+    // (recomputed where it is used -- all of them once-per-trial places -- instead of being held in
+    // registers across the hot loop)
+    auto err_buf = [&]() -> unsigned char* {
+        const int n4 = COLD(n_words4) * 4;
+        return reinterpret_cast<unsigned char*>(var_lds + DC * m) + (size_t)(sl + (err_par ? S : 0)) * n4;
+    };
 
     // ---- per-lane static tables (registers for the whole kernel) ---------------------------
     unsigned short nbr[DC][DV];
@@ -211,9 +219,16 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         *active_count = (int)(cnt < 0 ? 0 : (cnt > S ? S : cnt));
     }
 
+    // The lane's own check->variable messages are needed again in the variable step (Q = value - R).
+    // The headline shape keeps them in registers across barrier B1; the wider (8, 4) shape and the
+    // Monte-Carlo builds re-read them from LDS (a conflict-free ds_read per edge, no vector-ALU
+    // cost) instead of spending 2 * DC registers on them: that is what took those builds over the
+    // 128-register budget (scratch reloads inside a loop that is bound by vector-ALU issue).
+    constexpr bool HOLD_R = (DC <= 6) && !MC;
+
     // ---- per-syndrome state ---------------------------------------------------------------
     double Q[DC];
-    double R[DC];
+    double R[HOLD_R ? DC : 1];
     unsigned sbit = 0, ebits = 0;
     int it = 0;
     bool frozen = false;
@@ -225,6 +240,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         for (int j = 0; j < DC; ++j) Q[j] = pri_lds[j * m + c];   // Q = where(mask, initialBelief, 0)
         if constexpr (MC) {
             ebits = 0;
+            const unsigned char* const err_lds = err_buf();
 #pragma unroll
             for (int j = 0; j < DC; ++j) {
                 const int v = var_lds[j * m + c];
@@ -249,9 +265,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             // four qubits, by the first ceil(n/4) lanes of the slot; the extra barrier (Monte-Carlo
             // builds only) orders the bytes before the check lanes gather them.
             if (need_start) {
+                err_par ^= 1u;
+                unsigned* const err_words = reinterpret_cast<unsigned*>(err_buf());
                 const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
                 for (int g = c; g < P.n_words4; g += m)
-                    reinterpret_cast<unsigned*>(err_lds)[g] =
+                    err_words[g] =
                         mc_error_quad(trial, g, COLD(draws), COLD(seed), COLD(threshold));
             }
             __syncthreads();                                      // B0
@@ -286,14 +304,16 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 for (int j = 0; j < DC; ++j) {
                     const double s = Q[j] < 0.0 ? -1.0 : 1.0;
                     const double mag = (__builtin_fabs(Q[j]) == min1) ? min2 : min1;
-                    R[j] = (as * (sprod * s)) * mag;
+                    const double r = (as * (sprod * s)) * mag;
+                    Rs[j * m + c] = r;
+                    if constexpr (HOLD_R) R[j] = r;
                 }
             } else {
                 double t[DC];
                 double prod;
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
-                    t[j] = tanh_half(Q[j]);
+                    t[j] = tanh_half_msg<VARIANT>(Q[j]);
                     prod = (j == 0) ? t[0] : prod * t[j];         // np.prod, ascending column
                 }
 #pragma unroll
@@ -304,12 +324,12 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     double po = div_nr(prod, ts);
                     po = __hiloint2double(__double2hiint(po) ^ (int)(sbit << 31),
                                           __double2loint(po));   // * syndrome_sign
-                    const double r = atanh2(clipd(po, -0.9999999, 0.9999999));
-                    R[j] = (VARIANT == 1) ? r * P.alpha : r;
+                    double r = atanh2(clip_unit<VARIANT>(po));
+                    if (VARIANT == 1) r = r * P.alpha;
+                    Rs[j * m + c] = r;
+                    if constexpr (HOLD_R) R[j] = r;
                 }
             }
-#pragma unroll
-            for (int j = 0; j < DC; ++j) Rs[j * m + c] = R[j];
         }
         __syncthreads();                                          // B1
         if (*active_count == 0) break;
@@ -319,17 +339,21 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         if (active) {
             bool odd = sbit != 0;                                 // parity of the row vs syndrome
             // Issue the LDS gathers of a group of edges before the first add (one lgkmcnt wait per
-            // group instead of two per edge); groups of at most 18 gathers keep the (8, 4) shape
-            // inside the register budget.
-            constexpr int JG = (DC * DV <= 18) ? DC : (DC + 1) / 2;
+            // group instead of two per edge): all 18 for the (6, 3) shape, two edges (8 + 2 reads) at
+            // a time for the (8, 4) shape, whose register budget is the tighter constraint.
+            constexpr int JG = (DC * DV <= 18) ? DC : 2;
 #pragma unroll
             for (int j0 = 0; j0 < DC; j0 += JG) {
                 double rr[JG][DV];
+                double rown[HOLD_R ? 1 : JG];
 #pragma unroll
-                for (int jj = 0; jj < JG; ++jj)
+                for (int jj = 0; jj < JG; ++jj) {
 #pragma unroll
                     for (int k = 0; k < DV; ++k)
                         if (j0 + jj < DC) rr[jj][k] = Rs[nbr[j0 + jj][k]];
+                    if constexpr (!HOLD_R)
+                        if (j0 + jj < DC) rown[jj] = Rs[(j0 + jj) * m + c];
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int jj = 0; jj < JG; ++jj) {
@@ -340,7 +364,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     for (int k = 1; k < DV; ++k) s = s + rr[jj][k];   // ascending check order
                     val[j] = s + pri_lds[j * m + c];
                     odd ^= val[j] < 0.0;                              // hard decision: values < 0
-                    const double qn = val[j] - R[j];
+                    double r_own;
+                    if constexpr (HOLD_R) r_own = R[j]; else r_own = rown[jj];
+                    const double qn = val[j] - r_own;
                     if constexpr (VARIANT == 0) {
                         Q[j] = qn;
                     } else {
@@ -403,6 +429,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                                 f_err[o] = (uint8_t)((ebits >> j) & 1u);
                             }
                         }
+                        const unsigned char* const err_lds = err_buf();
                         for (int i = c; i < n_iso; i += m) {
                             const int v = COLD(iso_vars)[i];
                             const double pv = COLD(prior)[v];
@@ -429,6 +456,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                             if (e_out) e_out[row + v] = (uint8_t)e;
                         }
                     }
+                    const unsigned char* const err_lds = err_buf();
                     for (int i = c; i < n_iso; i += m) {
                         const int v = COLD(iso_vars)[i];
                         const unsigned e = err_lds[v];

@@ -174,4 +174,28 @@ QBP_HD double atanh2(double y)
     return __builtin_copysign(res, y);
 }
 
+// Variant-aware forms used by the kernels.  Plain sum-product (VARIANT 0) never produces a NaN
+// message from NaN-free priors (|R| is clipped, inf - finite = inf), so it keeps the two-instruction
+// min/max clip, which drops NaNs.  The damped variant (VARIANT 1, rework/decoding.py:131-191) can:
+// damping = 1 with an infinite prior gives Q = 1 * inf + 0 * inf = NaN (:179), and numpy then carries
+// the NaN through tanh, the row product, np.clip and arctanh into every message of that row.
+template <int VARIANT>
+QBP_HD double tanh_half_msg(double q)
+{
+    const double t = tanh_half(q);
+    if (VARIANT == 1) return q != q ? q : t;
+    return t;
+}
+
+template <int VARIANT>
+QBP_HD double clip_unit(double x)
+{
+    constexpr double C = 0.9999999;                      // beliefPropagation.py:110
+    if (VARIANT == 1) {
+        const double y = x < -C ? -C : x;                // np.clip: NaN stays NaN
+        return y > C ? C : y;
+    }
+    return __builtin_fmin(__builtin_fmax(x, -C), C);
+}
+
 }  // namespace qbp

@@ -121,7 +121,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
             double prod = 1.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                t[j] = tanh_half(q[j]);
+                t[j] = tanh_half_msg<VARIANT>(q[j]);
                 prod = (j == 0) ? t[0] : prod * t[j];            // np.prod, ascending column
             }
 #pragma unroll
@@ -129,7 +129,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
                 const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
                 double po = div_nr(prod, ts);
                 po = sbit ? -po : po;
-                const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+                const double r = atanh2(clip_unit<VARIANT>(po));
                 R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
             }
         }
@@ -167,7 +167,7 @@ __device__ __forceinline__ void stream_check_long(const double* Q, double* R, un
     } else {
         double prod = 1.0;
         for (int j = 0; j < deg; ++j) {
-            const double t = tanh_half(Q[(long long)(e0 + j) * ES]);
+            const double t = tanh_half_msg<VARIANT>(Q[(long long)(e0 + j) * ES]);
             R[(long long)(e0 + j) * ES] = t;
             prod = (j == 0) ? t : prod * t;
         }
@@ -176,7 +176,7 @@ __device__ __forceinline__ void stream_check_long(const double* Q, double* R, un
             const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
             double po = div_nr(prod, ts);
             po = sbit ? -po : po;
-            const double r = atanh2(__builtin_fmin(__builtin_fmax(po, -0.9999999), 0.9999999));
+            const double r = atanh2(clip_unit<VARIANT>(po));
             R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
         }
     }

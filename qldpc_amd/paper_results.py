@@ -73,17 +73,31 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)                             # :33-34
     ap.add_argument("--out", default="data/BPOSD_MI355X")
     ap.add_argument("--plot", action="store_true", help="two-panel figure as :169-185")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="N > 1 without a launcher: start N ranks (one per GPU) and reduce over RCCL")
+    ap.add_argument("--backend", default="nccl", help="nccl = RCCL; gloo only for rehearsals")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank on cuda:0")
     args = ap.parse_args(argv)
+
+    import sys
+    from . import launch
+    if argv is None:          # (a caller passing argv runs in-process, whatever --gpus says)
+        launch.maybe_self_launch(args.gpus, ["-m", "qldpc_amd.paper_results"] + sys.argv[1:])
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     if rank == 0:
         print(f"GPU Available: True ({world} x MI355X)")
         print(f"Running {args.trials} trials per point, BP maxIter {args.max_iter}, "

@@ -95,21 +95,46 @@ def test_paper_results_driver_end_to_end(tmp_path, capsys):
 
 
 def test_bench_two_rank_path(tmp_path):
-    """The N > 1 code path of bench.py (rank env, barrier, max-over-ranks timing, all-reduce of the
-    counts, rank-0 JSON line), rehearsed with two ranks sharing this GPU over gloo (RCCL refuses two
-    ranks on one device); the real multi-GPU run uses the same code with backend nccl."""
+    """`python bench.py --gpus 2` as typed: the process starts its own two ranks (qldpc_amd/launch.py)
+    and relays rank 0's JSON line.  Two ranks share this GPU over gloo here (RCCL refuses two ranks on
+    one device); on a multi-GPU node the same command runs with backend nccl = RCCL."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--share-device",
-           "--batch", "8000", "--mode", "forced", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--share-device", "--batch", "8000", "--mode", "forced",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["multi_gpu"]["n_ranks_seen"] == 2 and len(line["multi_gpu"]["kernel_ms_per_rank"]) == 2
+    assert line["multi_gpu"]["all_reduce_us"] > 0
     # (two ranks time-share one GPU and synchronise over gloo: not a performance number)
     assert line["value"] > 1e5 and line["config"]["syndromes_per_gpu_per_step"] == 8000
+
+
+def test_mc_two_rank_self_launch(tmp_path):
+    """`python -m qldpc_amd.mc --gpus 2` starts its own ranks; counters equal the one-rank run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    outs = []
+    for gpus in (1, 2):
+        f = str(tmp_path / f"mc{gpus}.json")
+        cmd = [sys.executable, "-m", "qldpc_amd.mc", "--code", "72", "--p", "0.05", "0.02", "--trials", "30001",
+               "--osd", "--gpus", str(gpus), "--backend", "gloo", "--share-device", "--out", f]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.load(open(f)))
+    assert outs[1]["world_size"] == 2
+    for a, b in zip(outs[0]["points"], outs[1]["points"]):
+        for k in ("trials", "logical_error", "not_converged", "sum_iterations", "BPs_miscorrected",
+                  "incorrectable"):
+            assert a[k] == b[k], k

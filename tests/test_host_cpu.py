@@ -235,3 +235,27 @@ def test_bench_accounting_and_committed_line():
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c
     assert line["value"] > 1e6            # the north star's floor
+
+
+def test_self_launch_command_and_supervisor(tmp_path):
+    """qldpc_amd/launch.py: `--gpus N` without a launcher becomes a supervisor of N child ranks
+    (torch.distributed.run on 127.0.0.1) BEFORE torch is imported; under a launcher it does nothing."""
+    import subprocess
+    import sys
+    from qldpc_amd import launch
+    cmd = launch.launcher_command(3, ["x.py", "--gpus", "3"], port=29999)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=3" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-3:] == ["x.py", "--gpus", "3"]
+    prog = tmp_path / "prog.py"
+    prog.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from qldpc_amd import launch\n"
+        "launch.maybe_self_launch(2, [os.path.abspath(__file__)])\n"
+        "assert 'torch' not in sys.modules\n"
+        "print('rank', os.environ['RANK'], 'of', os.environ['WORLD_SIZE'], flush=True)\n"
+        "sys.exit(7 if os.environ['RANK'] == '1' else 0)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, timeout=300, env=env)
+    assert "rank 0 of 2" in r.stdout and "rank 1 of 2" in r.stdout
+    assert r.returncode != 0          # a failing rank fails the supervisor
