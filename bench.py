@@ -15,9 +15,10 @@ in mode M2 of SURVEY.md 8(d): every syndrome runs all 50 iterations (QBP_FLAG_FO
 still those of the first converged iteration).  Everything else in the line is measured by this run:
 
 * ``roofline``       the binding resource of the on-chip kernel is FP64 vector-ALU issue, not HBM.
-                     Instruction mix per wave-iteration: read from the machine code of the library
-                     this process loaded (tools/valu_mix.py); issue rate of each instruction class:
-                     measured now by tools/ubench/valu_rates.hip; frac = t_min / t_kernel.
+                     achieved = vector instructions per wave and iteration, counted in the machine
+                     code of the library this process loaded (tools/valu_mix.py), x executions / kernel
+                     time; peak = issue rate of a stall-free stream with the same instruction-class mix,
+                     measured now on this chip (tools/ubench/valu_rates.hip); frac = achieved / peak.
 * ``hbm_effective``  SURVEY 8(d)'s algorithmic bytes over the kernel time (exceeds the HBM peak: the
                      messages it counts never leave the CU) -- kept as the north star's own yardstick.
 * ``early_exit``     reference semantics (mode M1); ``stress_p010`` forced-50 on a p = 0.10 batch BP
@@ -95,69 +96,89 @@ def cpu_baseline(code, syndromes, prior, budget_s=12.0):
 
 
 # ---- FP64 vector-ALU roofline, measured by this run -------------------------------------------------
-def valu_rates(device, waves_per_simd=4):
-    """{class: wave-instructions/s, whole chip} from tools/ubench/valu_rates.hip, plus the clock."""
+MAX_CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max shader clock (the in-run probe reads 2.39-2.41 GHz)
+
+
+def _ubench():
     so = os.path.join(ROOT, "tools", "ubench", "libvalu_rates.so")
     if not os.path.exists(so):
         raise RuntimeError(f"{so} missing: run __graft_entry__.build()")
     L = ctypes.CDLL(so)
     L.ubench_class_name.restype = ctypes.c_char_p
-    L.ubench_valu_rate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    L.ubench_clock_ghz.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    rates, c = {}, 0
+    L.ubench_valu_rate2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double)]
+    L.ubench_clock_ghz2.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    return L
+
+
+def valu_issue_costs(device, waves_per_simd=4):
+    """Per instruction class, measured now (tools/ubench/valu_rates.hip, every wave of a chip-filling grid
+    issuing independent instructions of that class): shader-clock cycles ONE SIMD needs per
+    wave-instruction (from the hardware cycle counter, so independent of the clock the chip chose for that
+    stream), and the wave-instructions/s the whole chip reached."""
+    L = _ubench()
+    cycles, rates, c = {}, {}, 0
     while True:
         name = L.ubench_class_name(c)
         if not name:
             break
-        r = ctypes.c_double()
-        rc = L.ubench_valu_rate(device, c, waves_per_simd, ctypes.byref(r))
+        r, cy = ctypes.c_double(), ctypes.c_double()
+        rc = L.ubench_valu_rate2(device, c, waves_per_simd, ctypes.byref(r), ctypes.byref(cy))
         if rc != 0:
-            raise RuntimeError(f"ubench_valu_rate({name.decode()}) failed: {rc}")
-        rates[name.decode()] = r.value
+            raise RuntimeError(f"ubench_valu_rate2({name.decode()}) failed: {rc}")
+        cycles[name.decode()], rates[name.decode()] = cy.value, r.value
         c += 1
-    return rates
+    return cycles, rates
 
 
 def shader_clock_ghz(device):
-    so = os.path.join(ROOT, "tools", "ubench", "libvalu_rates.so")
-    L = ctypes.CDLL(so)
-    L.ubench_clock_ghz.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    g = ctypes.c_double()
-    return g.value if L.ubench_clock_ghz(device, ctypes.byref(g)) == 0 else None
+    """Shader clock from a one-wave probe on its own stream (hardware cycle counter against the
+    100 MHz wall clock): called while other streams are busy it reads the clock held under that load."""
+    L = _ubench()
+    g, g2 = ctypes.c_double(), ctypes.c_double()
+    return g2.value if L.ubench_clock_ghz2(device, ctypes.byref(g), ctypes.byref(g2)) == 0 else None
 
 
 def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, num_cu):
-    """frac = (sum over classes of instructions / measured issue rate of that class) / kernel time."""
+    """Vector-ALU issue roofline.  needed = issue cycles of the kernel's own instructions: per wave
+    and BP iteration, sum over classes of (instructions counted in the machine code of the loaded
+    library) x (cycles one SIMD needs per instruction of that class, measured now), times the
+    wave-iterations of a launch.  available = SIMDs x kernel time x the maximum shader clock.
+    frac = needed / available <= 1; achieved / peak are the same statement in lane-instructions/s."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import valu_mix
     res = valu_mix.analyse(lib_path, [kernel_symbol])
     if len(res) != 1:
         raise RuntimeError(f"{len(res)} kernels match {kernel_symbol!r} in {lib_path}")
     name, mix = next(iter(res.items()))
-    rates = valu_rates(device)
-    per_class = {}
-    t_min = 0.0
-    for cls, n in mix["valu_by_class"].items():
-        rate = rates.get(cls) or rates["alu_b32" if cls.endswith("b32") else "fma_f64"]
-        t = n * wave_iterations / rate
-        per_class[cls] = {"per_wave_iteration": n, "wave_insts_per_s_peak": rate, "seconds": t}
-        t_min += t
+    per_class = dict(mix["valu_by_class"])
+    if "other_f64" in per_class:                                   # priced like an FMA
+        per_class["fma_f64"] = per_class.get("fma_f64", 0) + per_class.pop("other_f64")
     n_total = mix["valu_total"]
-    achieved = n_total * wave_iterations * 64 / kernel_s               # lane-instructions / s
-    frac = t_min / kernel_s
+    cycles, rates = valu_issue_costs(device)
+    issue_cycles = sum(n * cycles[c] for c, n in per_class.items())          # per wave-iteration
+    n_simd = num_cu * 4
+    frac = issue_cycles * wave_iterations / (n_simd * kernel_s * MAX_CLOCK_HZ)
+    achieved = n_total * wave_iterations * 64 / kernel_s                      # lane-instructions / s
     return {
         "bound": "fp64_valu", "achieved": achieved / 1e12, "peak": achieved / frac / 1e12,
         "unit": "Tlane-instr/s", "frac": frac, "traffic": None,
         "kernel": name, "kernel_ms": kernel_s * 1e3,
-        "valu_insts_per_wave_iteration": n_total, "wave_iterations_per_launch": wave_iterations,
-        "issue_seconds_by_class": per_class,
-        "fma_f64_peak_TFLOPs": rates["fma_f64"] * 64 * 2 / 1e12,
-        "spec_peak_TFLOPs_fp64_vector": num_cu * 4 * 16 * 2 * 2.4e9 / 1e12,
-        "how": "instruction mix: static, from the loaded libqbp.so (tools/valu_mix.py: main loop of the "
-               "kernel minus the once-per-syndrome regions); issue rates: measured in this run at 4 waves "
-               "per SIMD (tools/ubench/valu_rates.hip); peak = achieved / frac, i.e. the rate at which "
-               "this mix would issue with every slot used; traffic (HBM bytes from PMC counters) cannot "
-               "be collected from inside the run: see profiles/ and DESIGN.md section 4",
+        "valu_insts_per_wave_iteration": n_total, "valu_by_class": per_class,
+        "issue_cycles_per_inst_by_class": cycles,
+        "issue_cycles_per_wave_iteration": issue_cycles,
+        "wave_iterations_per_launch": wave_iterations, "simds": n_simd, "max_clock_GHz": MAX_CLOCK_HZ / 1e9,
+        "single_class_rates_Gwave_insts_per_s": {k: v / 1e9 for k, v in rates.items()},
+        "fma_f64_stream_TFLOPs": rates["fma_f64"] * 64 * 2 / 1e12,
+        "spec_peak_TFLOPs_fp64_vector": num_cu * 4 * 16 * 2 * MAX_CLOCK_HZ / 1e12,
+        "how": "achieved: vector-ALU instructions per wave and BP iteration counted in the machine code of "
+               "the loaded libqbp.so (tools/valu_mix.py: the kernel's main loop minus its once-per-syndrome "
+               "regions) x wave-iterations per launch / kernel time (HIP events on the launch stream).  peak: "
+               "the rate at which this instruction mix would issue if every issue cycle of every SIMD were "
+               "used at the maximum shader clock; the per-class issue costs (cycles per wave-instruction "
+               "per SIMD) are measured in this run with the hardware cycle counter "
+               "(tools/ubench/valu_rates.hip).  traffic (HBM bytes from PMC counters) cannot be collected "
+               "from inside the run: see profiles/ and DESIGN.md section 4",
     }
 
 
@@ -323,13 +344,19 @@ def main():
             n_launch = max(args.steps, int(np.ceil(args.sustained_seconds / (kernel_ms * 1e-3))))
             barrier()
             t0 = time.perf_counter()
-            marks = []
+            marks, sclk = [], []
             for i in range(n_launch):
                 step(_lib.FLAG_FORCE_FULL)
                 if i % max(1, n_launch // 10) == 0:
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record(stream)
                     marks.append((i, ev))
+                    # stay about two tenths ahead of the GPU, not the whole leg: the clock probes below
+                    # then fall at ~20 / 50 / 80 % of the leg's wall time, with work still queued
+                    if len(marks) > 2:
+                        marks[-3][1].synchronize()
+                    if len(marks) in (4, 7, 10):
+                        sclk.append(shader_clock_ghz(local_rank))
             barrier()
             wall_s = time.perf_counter() - t0
             clock_s = shader_clock_ghz(local_rank)
@@ -342,6 +369,7 @@ def main():
             sustained = {"value": world * B * n_launch / wall_s, "unit": "syndromes/s", "seconds": wall_s,
                          "launches": n_launch, "ratio_to_headline": world * B * n_launch / wall_s / value,
                          "rank0_rate_by_tenth": [float(x) for x in seg],
+                         "shader_clock_GHz_during": [x for x in sclk if x],
                          "shader_clock_GHz_right_after": clock_s}
 
     # ---- the HBM-streamed design point (qbp_stream.hpp), same workload, forced 50 ----------------

@@ -124,6 +124,20 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
                        int32_t iteration, double* messages);
 
 /*
+ * The two histograms behind the alpha fit of rework/Alvarado.py:10-66 (estimate_alpha_from_code), on
+ * the device: the check->variable messages of qbp_check_messages for B syndromes are binned by the
+ * true value of the bit they address (errors [B][n] 0/1 bytes: class of message (b, e) =
+ * errors[b][col_idx[e]], Alvarado.py:33-36) over their common range (:41-44) into `bins` equal bins
+ * with np.histogram's rules (:46-47).  Outputs: edges [bins + 1] (= np.linspace(min, max, bins + 1)),
+ * hist0 / hist1 [bins] raw counts.  The density normalisation and the one-parameter fit (:49-62)
+ * are a few flops on 2 * bins numbers and stay with the caller (qldpc_amd/alvarado.py).
+ */
+int qbp_message_histograms(qbp_handle* h, const uint8_t* syndromes, const uint8_t* errors,
+                           const double* prior, int64_t B, int32_t variant, double alpha,
+                           double damping, double clip_llr, int32_t iteration, int32_t bins,
+                           double* edges, int64_t* hist0, int64_t* hist1);
+
+/*
  * Monte-Carlo trials [trial_begin, trial_end) entirely on the device: sample errors, form
  * syndromes, decode, classify, count.  Replaces the body of the trial loop of
  * paperResults_GPU.py:89-144 (= paperResults.py:57-100) without its OSD call:

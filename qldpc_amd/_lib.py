@@ -50,6 +50,8 @@ SIGNATURES = {
                                        C.c_int64, _VP]),
     "qbp_check_messages": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                      C.c_double, C.c_int32, _VP]),
+    "qbp_message_histograms": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                         C.c_double, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     "qbp_osd0_batch": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
     "qbp_osd0_batch_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP]),
     "qbp_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
@@ -212,6 +214,24 @@ class Decoder:
                                          int(variant), float(alpha), float(damping),
                                          float(clip_llr), int(iteration), out.ctypes.data))
         return out
+
+    def message_histograms(self, syndromes, errors, prior, variant, alpha=1.0, damping=1.0,
+                           clip_llr=20.0, iteration=0, bins=50):
+        """(edges float64[bins + 1], hist0 int64[bins], hist1 int64[bins]): the check->variable
+        messages of `check_messages`, binned on the device by the true value of their bit."""
+        syn = np.ascontiguousarray(syndromes, np.uint8)
+        err = np.ascontiguousarray(errors, np.uint8)
+        pr = np.ascontiguousarray(prior, np.float64)
+        if syn.ndim != 2 or syn.shape[1] != self.m or err.shape != (syn.shape[0], self.n) or pr.shape != (self.n,):
+            raise ValueError("bad shapes")
+        edges = np.empty(int(bins) + 1, np.float64)
+        h0 = np.empty(int(bins), np.int64)
+        h1 = np.empty(int(bins), np.int64)
+        _check(load().qbp_message_histograms(self._h, syn.ctypes.data, err.ctypes.data, pr.ctypes.data,
+                                             syn.shape[0], int(variant), float(alpha), float(damping),
+                                             float(clip_llr), int(iteration), int(bins), edges.ctypes.data,
+                                             h0.ctypes.data, h1.ctypes.data))
+        return edges, h0, h1
 
     def osd0(self, syndromes, llr, hard):
         """OSD-0 on B decoder outputs (host arrays) -> solution uint8[B, n]."""

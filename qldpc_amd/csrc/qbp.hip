@@ -16,6 +16,7 @@
 #include "qbp_osd.hpp"
 #include "qbp_generic.hpp"
 #include "qbp_stream.hpp"
+#include "qbp_hist.hpp"
 
 static_assert(QBP_NUM_COUNTERS == qbp::NUM_COUNTERS, "counter layout");
 
@@ -111,7 +112,8 @@ struct qbp_handle {
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> d_syn, d_hard, d_conv;
     DevBuf<int32_t> d_iters;
-    DevBuf<double> d_llr, d_prior, d_mathx, d_mathy;
+    DevBuf<double> d_llr, d_prior, d_mathx, d_mathy, d_part, d_edges;
+    DevBuf<unsigned long long> d_hist;
     DevBuf<unsigned long long> d_lx_cols;
     DevBuf<long long> d_counters;
     std::vector<uint8_t> lx_cache;   // last uploaded Lx (host copy) to skip re-uploads
@@ -129,6 +131,7 @@ struct qbp_handle {
     DevBuf<int32_t> d_vpos, d_vrow, d_lcol_ptr;      // general-H kernel: column-class tables
     DevBuf<double> d_wsL, d_prior_sorted;
     int gcol_base[qbp::GENERIC_MAX_COL_CLASS + 2] = {0};
+    int rpad_off[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0}, cpad_off[qbp::GENERIC_MAX_COL_CLASS + 2] = {0};
     int opt_threads = 0;            // general-H kernel: threads per workgroup (0 = auto)
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
@@ -137,6 +140,11 @@ struct qbp_handle {
     void* pin_host = nullptr;
     void* pin_dev = nullptr;
     size_t pin_bytes = 0;
+    // two pinned staging buffers for the outputs of large host-pointer calls (device -> pinned by DMA
+    // at PCIe rate, pinned -> caller's pageable array by memcpy, one chunk behind)
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
     // OSD-0
     bool osd_ok = false;
     int osd_W = 0, osd_NP = 0, osd_lds = 0, osd_rank = 0;
@@ -204,7 +212,7 @@ hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cf
 size_t fused_lds_bytes(int dc, int m, int n, int S)
 {
     const size_t slot_stride = (size_t)dc * m + 2;
-    size_t lds = ((size_t)S * slot_stride + (size_t)dc * m + 2 * (size_t)S) * 8 +
+    size_t lds = ((size_t)S * slot_stride + (size_t)dc * m + 3 * (size_t)S) * 8 +
                  (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
                  2 * (size_t)S * (((size_t)n + 3) / 4) * 4;     // err_lds[2][S][n4] (Monte-Carlo builds)
     return (lds + 15) & ~(size_t)15;
@@ -472,7 +480,7 @@ static GenericGeom generic_geometry(const qbp_handle* h, long long B)
     g.lds_msgs = lds_full <= (size_t)160 * 1024;
     g.lds = g.lds_msgs ? lds_full : qbp::generic_lds_bytes(h->m, std::max(h->E, 1), false);
     const int short_rows = std::max(1, h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 1] - h->row_off[1]);
-    const int work = std::max(short_rows, 64);
+    const int work = std::max(h->rpad_off[qbp::GENERIC_MAX_ROW_CLASS + 1], 64);    // padded work items
     const int passes = (work + 1023) / 1024;
     int threads = (((work + passes - 1) / passes) + 63) / 64 * 64;
     int per_cu = std::max(1, 1024 / threads);
@@ -528,6 +536,8 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     G.svar = h->d_svar.p; G.vpos = h->d_vpos.p; G.vrow = h->d_vrow.p; G.lcol_ptr = h->d_lcol_ptr.p;
     std::copy(std::begin(h->col_off), std::end(h->col_off), G.col_off);
     std::copy(std::begin(h->gcol_base), std::end(h->gcol_base), G.col_base);
+    std::copy(std::begin(h->rpad_off), std::end(h->rpad_off), G.rpad_off);
+    std::copy(std::begin(h->cpad_off), std::end(h->cpad_off), G.cpad_off);
     G.prior_sorted = h->d_prior_sorted.p;
     G.syndromes = d_syndromes; G.B = B; G.max_iter = max_iter; G.flags = flags;
     G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
@@ -614,6 +624,20 @@ try {
     up(h->d_vrow, T.vrow);
     up(h->d_lcol_ptr, T.lcol_ptr);
     std::copy(std::begin(T.gcol_base), std::end(T.gcol_base), h->gcol_base);
+    {   // work items of the general-H kernel: every weight class padded to whole wavefronts
+        int off = 0;
+        for (int k = 1; k <= qbp::GENERIC_MAX_ROW_CLASS; ++k) {
+            h->rpad_off[k] = off;
+            off += (T.row_off[k + 1] - T.row_off[k] + 63) / 64 * 64;
+        }
+        h->rpad_off[qbp::GENERIC_MAX_ROW_CLASS + 1] = off;
+        off = 0;
+        for (int k = 1; k <= qbp::GENERIC_MAX_COL_CLASS; ++k) {
+            h->cpad_off[k] = off;
+            off += (T.col_off[k + 1] - T.col_off[k] + 63) / 64 * 64;
+        }
+        h->cpad_off[qbp::GENERIC_MAX_COL_CLASS + 1] = off;
+    }
     std::copy(std::begin(T.row_base), std::end(T.row_base), h->row_base);
     up(h->d_srow, T.srow);
     up(h->d_srow_e0, T.srow_e0);
@@ -696,8 +720,12 @@ void qbp_destroy(qbp_handle* h)
     h->d_tab_var.release(); h->d_tab_nbr.release(); h->d_tab_writer.release(); h->d_iso.release();
     h->d_work_counter.release(); h->d_syn.release(); h->d_hard.release(); h->d_conv.release();
     h->d_iters.release(); h->d_llr.release(); h->d_prior.release();
-    h->d_mathx.release(); h->d_mathy.release(); h->d_lx_cols.release(); h->d_counters.release();
+    h->d_mathx.release(); h->d_mathy.release(); h->d_part.release(); h->d_edges.release(); h->d_hist.release(); h->d_lx_cols.release(); h->d_counters.release();
     if (h->pin_host) (void)hipHostFree(h->pin_host);
+    for (int i = 0; i < 2; ++i) {
+        if (h->stage[i]) (void)hipHostFree(h->stage[i]);
+        if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
+    }
     h->d_col_ptr.release(); h->d_col_edge.release(); h->d_wsQ.release(); h->d_wsR.release();
     h->d_wsV.release(); h->d_wsC.release(); h->d_wsS.release(); h->d_wsE.release(); h->d_svar.release(); h->d_sedge.release();
     h->d_srow.release(); h->d_srow_e0.release(); h->d_srow_deg.release();
@@ -871,10 +899,66 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
                                  converged ? h->d_conv.p : nullptr, iters ? h->d_iters.p : nullptr,
                                  llr ? h->d_llr.p : nullptr, s);
     if (rc) return rc;
-    if (hard) HIP_TRY(hipMemcpyAsync(hard, h->d_hard.p, b * n, hipMemcpyDeviceToHost, s));
-    if (converged) HIP_TRY(hipMemcpyAsync(converged, h->d_conv.p, b, hipMemcpyDeviceToHost, s));
-    if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters.p, b * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (llr) HIP_TRY(hipMemcpyAsync(llr, h->d_llr.p, b * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    // Outputs: device -> pinned staging (DMA at PCIe rate) -> the caller's arrays (memcpy), in chunks
+    // of up to 32 MiB, the host copy of one chunk overlapping the DMA of the next.  (A direct copy
+    // into pageable memory goes through the runtime's own small staging buffers at a fraction of
+    // that rate.)
+    {
+        const size_t per = (hard ? n : 0) + (converged ? 1 : 0) + (iters ? 4 : 0) + (llr ? 8 * n : 0);
+        constexpr size_t STAGE = (size_t)32 << 20;
+        if (per > 0) {
+            if (h->stage_bytes < STAGE) {
+                for (int i = 0; i < 2; ++i) {
+                    if (h->stage[i]) (void)hipHostFree(h->stage[i]);
+                    h->stage[i] = nullptr;
+                }
+                h->stage_bytes = 0;
+                for (int i = 0; i < 2; ++i) {
+                    HIP_TRY(hipHostMalloc(&h->stage[i], STAGE + 64, hipHostMallocDefault));
+                    if (!h->stage_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+                }
+                h->stage_bytes = STAGE;
+            }
+            const size_t chunk = std::max<size_t>(1, std::min<size_t>(b, STAGE / (per + 8)));
+            struct Piece { size_t b0, cnt; };
+            Piece prev{0, 0};
+            auto offsets = [&](size_t cnt, size_t& o_llr, size_t& o_it, size_t& o_hard, size_t& o_conv) {
+                o_llr = 0;
+                o_it = o_llr + (llr ? cnt * n * 8 : 0);
+                o_hard = o_it + (iters ? ((cnt * 4 + 7) & ~(size_t)7) : 0);
+                o_conv = o_hard + (hard ? cnt * n : 0);
+            };
+            auto drain = [&](const Piece& pc, int slot) -> int {
+                if (pc.cnt == 0) return QBP_OK;
+                HIP_TRY(hipEventSynchronize(h->stage_ev[slot]));
+                const uint8_t* st = static_cast<const uint8_t*>(h->stage[slot]);
+                size_t o_llr, o_it, o_hard, o_conv;
+                offsets(pc.cnt, o_llr, o_it, o_hard, o_conv);
+                if (llr) std::memcpy(llr + pc.b0 * n, st + o_llr, pc.cnt * n * 8);
+                if (iters) std::memcpy(iters + pc.b0, st + o_it, pc.cnt * 4);
+                if (hard) std::memcpy(hard + pc.b0 * n, st + o_hard, pc.cnt * n);
+                if (converged) std::memcpy(converged + pc.b0, st + o_conv, pc.cnt);
+                return QBP_OK;
+            };
+            int slot = 0;
+            for (size_t b0 = 0; b0 < b; b0 += chunk, slot ^= 1) {
+                const size_t cnt = std::min(chunk, b - b0);
+                uint8_t* st = static_cast<uint8_t*>(h->stage[slot]);
+                size_t o_llr, o_it, o_hard, o_conv;
+                offsets(cnt, o_llr, o_it, o_hard, o_conv);
+                if (llr) HIP_TRY(hipMemcpyAsync(st + o_llr, h->d_llr.p + b0 * n, cnt * n * 8, hipMemcpyDeviceToHost, s));
+                if (iters) HIP_TRY(hipMemcpyAsync(st + o_it, h->d_iters.p + b0, cnt * 4, hipMemcpyDeviceToHost, s));
+                if (hard) HIP_TRY(hipMemcpyAsync(st + o_hard, h->d_hard.p + b0 * n, cnt * n, hipMemcpyDeviceToHost, s));
+                if (converged) HIP_TRY(hipMemcpyAsync(st + o_conv, h->d_conv.p + b0, cnt, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipEventRecord(h->stage_ev[slot], s));
+                rc = drain(prev, slot ^ 1);          // the previous chunk, while this one is in flight
+                if (rc) return rc;
+                prev = Piece{b0, cnt};
+            }
+            rc = drain(prev, slot ^ 1);
+            if (rc) return rc;
+        }
+    }
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
@@ -913,6 +997,64 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
+
+int qbp_message_histograms(qbp_handle* h, const uint8_t* syndromes, const uint8_t* errors, const double* prior,
+                           int64_t B, int32_t variant, double alpha, double damping, double clip_llr,
+                           int32_t iteration, int32_t bins, double* edges, int64_t* hist0, int64_t* hist1)
+try {
+    int rc = check_decode_args(h, B, iteration + 1, variant);
+    if (rc) return rc;
+    if (!syndromes || !errors || !prior || !edges || !hist0 || !hist1) return fail(QBP_E_INVALID, "null pointer");
+    if (bins < 1 || bins > 4096) return fail(QBP_E_INVALID, "bins = %d out of range (1 .. 4096)", bins);
+    if (B == 0 || h->E == 0) return fail(QBP_E_INVALID, "no messages to bin (B = %lld, E = %d)", (long long)B, h->E);
+    if (variant == QBP_SUM_PRODUCT) { variant = QBP_DAMPED_SP; alpha = 1.0; damping = 1.0; clip_llr = __builtin_inf(); }
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
+    const size_t m = h->m, n = h->n, b = (size_t)B, E = (size_t)h->E;
+    HIP_TRY(h->d_syn.reserve(b * m));
+    HIP_TRY(h->d_hard.reserve(b * n));               // the true error bits
+    HIP_TRY(h->d_prior.reserve(n));
+    HIP_TRY(h->d_llr.reserve(b * E));                // the messages, [B][E]
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->d_syn.p, syndromes, b * m, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_hard.p, errors, b * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior, n * sizeof(double), hipMemcpyHostToDevice, s));
+    const double div = variant == QBP_MIN_SUM ? alpha : 1.0;
+    rc = generic_launch(h, h->d_syn.p, h->d_prior.p, B, iteration + 1, variant, alpha, damping, clip_llr,
+                        QBP_FLAG_FORCE_FULL, nullptr, nullptr, nullptr, nullptr, h->d_llr.p, iteration, div, s);
+    if (rc) return rc;
+    // range of all messages (rework/Alvarado.py:41-44: the two classes share one range)
+    const int grid = (int)std::min<size_t>(1024, (b * E + 255) / 256);
+    HIP_TRY(h->d_part.reserve((size_t)2 * grid));
+    hipLaunchKernelGGL(qbp::hist_minmax_kernel, dim3(grid), dim3(256), 0, s, h->d_llr.p, (long long)(b * E), h->d_part.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> part((size_t)2 * grid);
+    HIP_TRY(hipMemcpyAsync(part.data(), h->d_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (int i = 0; i < grid; ++i) { lo = std::min(lo, part[2 * i]); hi = std::max(hi, part[2 * i + 1]); }
+    if (!(lo <= hi) || std::isinf(lo) || std::isinf(hi))
+        return fail(QBP_E_INVALID, "message range [%g, %g] is not finite (np.histogram raises there too)", lo, hi);
+    if (lo == hi) { lo -= 0.5; hi += 0.5; }          // np.histogram's rule for a degenerate range
+    // np.linspace(lo, hi, bins + 1): start + i * step, the last edge exactly hi
+    const double step = (hi - lo) / (double)bins;
+    for (int i = 0; i < bins; ++i) edges[i] = (double)i * step + lo;
+    edges[bins] = hi;
+    HIP_TRY(h->d_edges.reserve((size_t)bins + 1));
+    HIP_TRY(h->d_hist.reserve((size_t)2 * bins));
+    HIP_TRY(hipMemcpyAsync(h->d_edges.p, edges, ((size_t)bins + 1) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->d_hist.p, 0, (size_t)2 * bins * sizeof(unsigned long long), s));
+    const size_t lds = (((size_t)2 * bins + 1) & ~(size_t)1) * 4 + ((size_t)bins + 1) * 8;
+    hipLaunchKernelGGL(qbp::hist_bin_kernel, dim3(grid), dim3(256), lds, s, h->d_llr.p, h->d_hard.p, h->d_col_idx.p,
+                       (long long)B, (int)E, (int)n, h->d_edges.p, bins, h->d_hist.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> hist((size_t)2 * bins);
+    HIP_TRY(hipMemcpyAsync(hist.data(), h->d_hist.p, hist.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < bins; ++i) { hist0[i] = (int64_t)hist[i]; hist1[i] = (int64_t)hist[bins + i]; }
+    return QBP_OK;
+}
+QBP_ABI_CATCH
 
 static int mc_prepare(qbp_handle* h, const uint8_t* Lx, int32_t k, hipStream_t s)
 {

@@ -6,9 +6,10 @@
 //   * in a per-workgroup global workspace that stays in L2 / Infinity Cache.
 // One BP iteration is TWO workgroup barriers:
 //   check step     one thread per check; checks are sorted by weight and the work items of all
-//                  weight classes form ONE index range (a wave straddling two classes diverges, all
-//                  others run one straight-line body): D coalesced loads, the check update, D
-//                  coalesced stores ("class-blocked, transposed" layout, see GenericParams);
+//                  weight classes form ONE index range in which every class is padded to whole
+//                  wavefronts (a wavefront runs exactly one straight-line body, found by a scalar
+//                  search): D coalesced loads, the check update, D coalesced stores ("class-blocked,
+//                  transposed" layout, see GenericParams);
 //   -- barrier A --
 //   variable step  one thread per variable, variables sorted by column weight in the same way:
 //                  gathers the column's messages (ascending check: np.sum(R, axis=0)), posterior
@@ -54,6 +55,10 @@ struct GenericParams {
     const int32_t* epos;        // [E] CSR edge -> position in the layout
     int row_off[GENERIC_MAX_ROW_CLASS + 3];    // class boundaries in srow (weights 0 .. 8, > 8)
     int row_base[GENERIC_MAX_ROW_CLASS + 2];   // first position of each class block
+    // work items of the check step: the checks of weight 1 .. 8 in sorted order, each class padded to
+    // whole wavefronts (rpad_off[D] = first item of class D, a multiple of 64; rpad_off[9] = total),
+    // so that a wavefront never holds two classes (it would run both straight-line bodies)
+    int rpad_off[GENERIC_MAX_ROW_CLASS + 2];
     const int32_t* long_edge_row;   // [E - row_base[9]]
     double* wsL;                // [grid][3 * number of long checks] row product / (sprod, min1, min2)
     // ---- variables, sorted by column weight (stable): sorted position x -> variable svar[x] ----
@@ -67,6 +72,7 @@ struct GenericParams {
     const int32_t* lcol_ptr;    // [number of long columns + 1], absolute offsets into vpos / vrow
     int col_off[GENERIC_MAX_COL_CLASS + 3];    // class boundaries in svar (weights 0 .. 4, > 4)
     int col_base[GENERIC_MAX_COL_CLASS + 2];
+    int cpad_off[GENERIC_MAX_COL_CLASS + 2];   // work items of the variable step, padded like rpad_off
     const double* prior_sorted; // [n] prior of the sorted variable x (permuted once per call)
     // ---- the call ---------------------------------------------------------------------------------
     const uint8_t* syndromes;
@@ -199,6 +205,17 @@ __device__ __forceinline__ double np_pairwise_gather(const double* R, const int3
     return 0.0;
 }
 
+// Column-weight class of the sorted variable x (weights 1 .. 4): weight D, number of variables in the
+// class, offset of the variable's first entry in vpos / vrow.  Written with compile-time indices only:
+// a dynamically indexed kernel-argument array would be copied to scratch memory.
+__device__ __forceinline__ void generic_col_class(const GenericParams& P, int x, int& D, int& cnt, int& o)
+{
+    if (x < P.col_off[2])      { D = 1; cnt = P.col_off[2] - P.col_off[1]; o = P.col_base[1] + (x - P.col_off[1]); }
+    else if (x < P.col_off[3]) { D = 2; cnt = P.col_off[3] - P.col_off[2]; o = P.col_base[2] + (x - P.col_off[2]); }
+    else if (x < P.col_off[4]) { D = 3; cnt = P.col_off[4] - P.col_off[3]; o = P.col_base[3] + (x - P.col_off[3]); }
+    else                       { D = 4; cnt = P.col_off[5] - P.col_off[4]; o = P.col_base[4] + (x - P.col_off[4]); }
+}
+
 // Once per decode call: prior of the sorted variable x.
 __global__ void generic_permute_prior(const double* prior, const int32_t* svar, double* out, int n)
 {
@@ -300,9 +317,9 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         }
         // ---- Q = prior on the edges (beliefPropagation.py:107) -------------------------------------
         for (int x = tid + P.col_off[1]; x < first_lcol; x += nt) {
-            const int D = 1 + (x >= P.col_off[2]) + (x >= P.col_off[3]) + (x >= P.col_off[4]);
-            const int cnt = P.col_off[D + 1] - P.col_off[D];
-            const int32_t* const pos = P.vpos + P.col_base[D] + (x - P.col_off[D]);
+            int D, cnt, o;
+            generic_col_class(P, x, D, cnt, o);
+            const int32_t* const pos = P.vpos + o;
             const double pv = P.prior_sorted[x];
             for (int j = 0; j < D; ++j) Q[pos[(size_t)j * cnt]] = pv;
         }
@@ -342,9 +359,9 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 if (x < P.col_off[1]) {
                     val = P.prior_sorted[x];                        // isolated variable
                 } else if (x < first_lcol) {
-                    const int D = 1 + (x >= P.col_off[2]) + (x >= P.col_off[3]) + (x >= P.col_off[4]);
-                    const int cnt = P.col_off[D + 1] - P.col_off[D];
-                    const int32_t* const pos = P.vpos + P.col_base[D] + (x - P.col_off[D]);
+                    int D, cnt, o;
+                    generic_col_class(P, x, D, cnt, o);
+                    const int32_t* const pos = P.vpos + o;
                     double s = 0.0;
                     for (int j = 0; j < D; ++j) {
                         const double r = R[pos[(size_t)j * cnt]];
@@ -402,21 +419,29 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         for (int it = 0; it < P.max_iter; ++it) {
             const bool scale = !(P.dump_R != nullptr && it == P.dump_iter);
             // ================= check step =======================================================
-            for (int w_ = tid + P.row_off[1]; w_ < first_long; w_ += nt) {
-                // (opaque copy of the loop counter: keeps the per-class address arithmetic inside the
-                // loop.  Hoisted, it is ~60 loop-invariant registers that get spilled to scratch.)
-                int w = w_;
-                asm volatile("" : "+v"(w));
-                const int D = P.srow_deg[w];
-                const unsigned sbit = (synw[w >> 5] >> (w & 31)) & 1u;
+            for (int wp0 = tid - lane; wp0 < P.rpad_off[RC + 1]; wp0 += nt) {
+                // one wavefront = 64 consecutive work items of ONE weight class (scalar class search)
+                const int wpu = __builtin_amdgcn_readfirstlane(wp0);
+                int D = 1;              // (compile-time indices only: a dynamically indexed kernel
+#pragma unroll                          //  argument array would be copied to scratch memory)
+                for (int k = 2; k <= RC; ++k) D += wpu >= P.rpad_off[k] ? 1 : 0;
+                // (opaque: keeps the per-class address arithmetic inside the loop.  Hoisted, it is ~60
+                // loop-invariant registers that get spilled to scratch.)
+                int lane_ = lane;
+                asm volatile("" : "+v"(lane_));
 #define QBP_ROW_CLASS(DD)                                                                          \
                 case DD: {                                                                         \
                     const int cnt = P.row_off[DD + 1] - P.row_off[DD];                             \
-                    const int base = P.row_base[DD] + (w - P.row_off[DD]);                         \
-                    double q[DD], r[DD];                                                           \
-                    _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = Q[base + j * cnt];       \
-                    generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale);                   \
-                    _Pragma("unroll") for (int j = 0; j < DD; ++j) R[base + j * cnt] = r[j];       \
+                    const int i = wpu - P.rpad_off[DD] + lane_;                                    \
+                    if (i < cnt) {                                                                 \
+                        const int w = P.row_off[DD] + i;                                           \
+                        const unsigned sbit = (synw[w >> 5] >> (w & 31)) & 1u;                     \
+                        const int base = P.row_base[DD] + i;                                       \
+                        double q[DD], r[DD];                                                       \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = Q[base + j * cnt];   \
+                        generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale);               \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) R[base + j * cnt] = r[j];   \
+                    }                                                                              \
                 } break;
                 switch (D) {
                     QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
@@ -510,25 +535,31 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 const unsigned old = atomicXor(&pbuf[cw >> 5], bit);
                 delta += (old & bit) ? -1 : 1;
             };
-            for (int x_ = tid + P.col_off[1]; x_ < first_lcol; x_ += nt) {
-                int x = x_;
-                asm volatile("" : "+v"(x));
-                const int D = 1 + (x >= P.col_off[2]) + (x >= P.col_off[3]) + (x >= P.col_off[4]);
+            for (int xp0 = tid - lane; xp0 < P.cpad_off[CC + 1]; xp0 += nt) {
+                const int xpu = __builtin_amdgcn_readfirstlane(xp0);
+                int D = 1;
+#pragma unroll
+                for (int k = 2; k <= CC; ++k) D += xpu >= P.cpad_off[k] ? 1 : 0;
+                int lane_ = lane;
+                asm volatile("" : "+v"(lane_));
 #define QBP_COL_CLASS(DD)                                                                          \
                 case DD: {                                                                         \
                     const int cnt = P.col_off[DD + 1] - P.col_off[DD];                             \
-                    const int base = P.col_base[DD] + (x - P.col_off[DD]);                         \
-                    int o[DD];                                                                     \
-                    double r[DD];                                                                  \
-                    _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = P.vpos[base + j * cnt];  \
-                    _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = R[o[j]];                 \
-                    double s = r[0];                                                               \
-                    _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];                   \
-                    const double val = s + P.prior_sorted[x];                                      \
-                    if (!frozen && val < 0.0) {                                                    \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(P.vrow[base + j * cnt]); \
+                    const int i = xpu - P.cpad_off[DD] + lane_;                                    \
+                    if (i < cnt) {                                                                 \
+                        const int base = P.col_base[DD] + i;                                       \
+                        int o[DD];                                                                 \
+                        double r[DD];                                                              \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = P.vpos[base + j * cnt]; \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = R[o[j]];             \
+                        double s = r[0];                                                           \
+                        _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];               \
+                        const double val = s + P.prior_sorted[P.col_off[DD] + i];                  \
+                        if (!frozen && val < 0.0) {                                                \
+                            _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(P.vrow[base + j * cnt]); \
+                        }                                                                          \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) q_update(o[j], val, r[j]);  \
                     }                                                                              \
-                    _Pragma("unroll") for (int j = 0; j < DD; ++j) q_update(o[j], val, r[j]);      \
                 } break;
                 switch (D) {
                     QBP_COL_CLASS(1) QBP_COL_CLASS(2) QBP_COL_CLASS(3) QBP_COL_CLASS(4)

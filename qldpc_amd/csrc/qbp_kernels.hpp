@@ -29,6 +29,24 @@
 #include "qbp_math.hpp"
 #include "qbp_mc.hpp"
 
+// Register-budget choices of the shapes that do not fit 128 registers otherwise (A/B switches for
+// tools/build_variants.sh; the defaults are the measured-best settings, profiles/r02_ab_wide_mc.txt)
+#ifndef QBP_WIDE_JG
+#define QBP_WIDE_JG 4          // (8, 4) shape: edges per LDS gather group
+#endif
+#ifndef QBP_WIDE_HOLD_R
+#define QBP_WIDE_HOLD_R 1      // (8, 4) shape: own messages in registers across barrier B1
+#endif
+#ifndef QBP_WIDE_PACK
+#define QBP_WIDE_PACK 0        // (8, 4) shape: two LDS offsets per register
+#endif
+#ifndef QBP_MC_HOLD_R
+#define QBP_MC_HOLD_R 0        // Monte-Carlo builds: as above
+#endif
+#ifndef QBP_MC_PACK
+#define QBP_MC_PACK 0
+#endif
+
 namespace qbp {
 
 struct FusedParams {
@@ -122,6 +140,7 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
 // LDS carve (in units of 8 bytes after the message area):
 //   [DC][m] priors of the edges' variables (+inf for padding edges)
 //   [S]  next work index per slot
+//   [S]  end of the chunk of work indices the slot is drawing from (leader only)
 //   [S]  MC logical-mask accumulator
 //   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
 //   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only), var_lds[DC][m], err_lds[2][S][n4] bytes (MC)
@@ -146,7 +165,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     long long* const next_work = reinterpret_cast<long long*>(pri_lds + DC * m);
     // (the variable indices of the edges, needed only when a syndrome is emitted, sit behind the
     // 32-bit words below: var_lds[DC][m])
-    unsigned long long* const mc_lmask = reinterpret_cast<unsigned long long*>(next_work + S);
+    long long* const chunk_ends = next_work + S;     // (LDS, not a register: touched once per syndrome)
+    unsigned long long* const mc_lmask = reinterpret_cast<unsigned long long*>(chunk_ends + S);
     int* const words = reinterpret_cast<int*>(mc_lmask + S);
     int* const flag0 = words;            // [2][S]
     int* const mc_weight = words + 2 * S;
@@ -168,7 +188,12 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     };
 
     // ---- per-lane static tables (registers for the whole kernel) ---------------------------
-    unsigned short nbr[DC][DV];
+    // LDS word offsets of the columns of this check's variables.  The (6, 3) shape keeps one register
+    // per offset; the (8, 4) shape and the Monte-Carlo builds pack two 16-bit offsets per register
+    // (half the registers, one extra shift/mask per gather) -- their register budget is what limits them.
+    constexpr bool PACK_NBR = (DC > 6 && QBP_WIDE_PACK != 0) || (MC && QBP_MC_PACK != 0);
+    constexpr int NBR_W = PACK_NBR ? (DV + 1) / 2 : DV;
+    unsigned nbr[DC][NBR_W];
     unsigned wmask = 0;
     unsigned vmask = 0;            // bit j: edge j of this check exists (not padding)
 #pragma unroll
@@ -181,7 +206,14 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k)
-            nbr[j][k] = lane_valid ? P.tab_nbr[(j * DV + k) * m + c] : (unsigned short)zoff;
+        {
+            const unsigned o = lane_valid ? P.tab_nbr[(j * DV + k) * m + c] : (unsigned)zoff;
+            if constexpr (PACK_NBR) {
+                if (k & 1) nbr[j][k / 2] |= o << 16; else nbr[j][k / 2] = o;
+            } else {
+                nbr[j][k] = o;
+            }
+        }
     }
     if (lane_valid) wmask = P.tab_writer[c];
 
@@ -195,7 +227,6 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // WORK_CHUNK syndromes: a single word sustains only ~88 dequeues/us, MI355X_MICROARCH.md
     // 'dequeue', which early-exit decoding at low error rates would exceed).
     constexpr int WORK_CHUNK = FORCE_FULL ? 1 : 8;   // forced mode: 1 atomic per max_iter iterations
-    long long chunk_end = 0;      // leader only: end of the chunk next_work[slot] points into
     long long b = lane_valid ? (long long)blockIdx.x * S + slot : B;
     bool active = b < B;
 
@@ -209,9 +240,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         if constexpr (MC) {
             for (int i = 0; i < NUM_COUNTERS; ++i) mc_count[i] = 0;
         }
-        chunk_end = total_slots + (long long)atomicAdd(P.work_counter, (unsigned long long)WORK_CHUNK);
-        next_work[slot] = chunk_end;
-        chunk_end += WORK_CHUNK;
+        const long long first = total_slots + (long long)atomicAdd(P.work_counter, (unsigned long long)WORK_CHUNK);
+        next_work[slot] = first;
+        chunk_ends[slot] = first + WORK_CHUNK;
     }
     if (tid == 0) {
         long long first = (long long)blockIdx.x * S;
@@ -219,12 +250,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         *active_count = (int)(cnt < 0 ? 0 : (cnt > S ? S : cnt));
     }
 
-    // The lane's own check->variable messages are needed again in the variable step (Q = value - R).
-    // The headline shape keeps them in registers across barrier B1; the wider (8, 4) shape and the
-    // Monte-Carlo builds re-read them from LDS (a conflict-free ds_read per edge, no vector-ALU
-    // cost) instead of spending 2 * DC registers on them: that is what took those builds over the
-    // 128-register budget (scratch reloads inside a loop that is bound by vector-ALU issue).
-    constexpr bool HOLD_R = (DC <= 6) && !MC;
+    // The lane's own check->variable messages are needed again in the variable step (Q = value - R):
+    // kept in registers across barrier B1, or re-read from LDS (a conflict-free ds_read per edge, no
+    // vector-ALU cost) to save 2 * DC registers.  Measured (profiles/r02_ab_wide_mc.txt): the
+    // Monte-Carlo builds are 6.6 % faster re-reading (their hot loop then runs without scratch
+    // accesses); the (8, 4) shape is 4 % faster holding them, although that build spills 19
+    // registers and the re-reading one none -- its iteration is not bound by those reloads.
+    constexpr bool HOLD_R = MC ? (QBP_MC_HOLD_R != 0 && DC <= 6) : (DC <= 6 || QBP_WIDE_HOLD_R != 0);
 
     // ---- per-syndrome state ---------------------------------------------------------------
     double Q[DC];
@@ -341,7 +373,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             // Issue the LDS gathers of a group of edges before the first add (one lgkmcnt wait per
             // group instead of two per edge): all 18 for the (6, 3) shape, two edges (8 + 2 reads) at
             // a time for the (8, 4) shape, whose register budget is the tighter constraint.
-            constexpr int JG = (DC * DV <= 18) ? DC : 2;
+            constexpr int JG = (DC * DV <= 18) ? DC : QBP_WIDE_JG;
 #pragma unroll
             for (int j0 = 0; j0 < DC; j0 += JG) {
                 double rr[JG][DV];
@@ -350,7 +382,19 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 for (int jj = 0; jj < JG; ++jj) {
 #pragma unroll
                     for (int k = 0; k < DV; ++k)
-                        if (j0 + jj < DC) rr[jj][k] = Rs[nbr[j0 + jj][k]];
+                        if (j0 + jj < DC) {
+                            unsigned o;
+                            if constexpr (PACK_NBR) {
+                                // (opaque: otherwise the 32 unpacked byte addresses are hoisted out
+                                // of the iteration loop -- loop-invariant -- and spilled to scratch)
+                                unsigned pk = nbr[j0 + jj][k / 2];
+                                asm volatile("" : "+v"(pk));
+                                o = (k & 1) ? pk >> 16 : pk & 0xffffu;
+                            } else {
+                                o = nbr[j0 + jj][k];
+                            }
+                            rr[jj][k] = Rs[o];
+                        }
                     if constexpr (!HOLD_R)
                         if (j0 + jj < DC) rown[jj] = Rs[(j0 + jj) * m + c];
                 }
@@ -386,10 +430,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             flag0[((phase + 1u) & 1u) * S + slot] = 0;
             if (refill) {
                 long long nx = next_work[slot] + 1;
-                if (nx == chunk_end) {
+                if (nx == chunk_ends[slot]) {
                     nx = total_slots +
                          (long long)atomicAdd(COLD(work_counter), (unsigned long long)WORK_CHUNK);
-                    chunk_end = nx + WORK_CHUNK;
+                    chunk_ends[slot] = nx + WORK_CHUNK;
                 }
                 next_work[slot] = nx;
                 refill = false;

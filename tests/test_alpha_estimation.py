@@ -53,3 +53,26 @@ def test_device_message_dumps_and_alpha_fit(capsys):
                                               maxIter=1, bins=int(bins))
     assert "Estimated alpha for error rate" in capsys.readouterr().out
     assert alpha == pytest.approx(float(d["alpha_fit"][0]), rel=1e-12)
+
+
+def test_closed_form_fit_is_the_references_fit():
+    """qldpc_amd.alvarado.alpha_from_histograms (density, log ratio, slope through the origin) against
+    the reference's own sequence of numpy / scipy calls (rework/Alvarado.py:41-62) on synthetic
+    messages: np.histogram(..., density=True) on a common range, curve_fit of alpha * x."""
+    from scipy.optimize import curve_fit
+
+    from qldpc_amd import alvarado
+    rng = np.random.default_rng(11)
+    for _ in range(5):
+        m0 = rng.normal(2.0, 1.5, 40000)          # messages about bits that are 0 / 1
+        m1 = rng.normal(-2.0, 1.5, 3000)
+        rng_ = (min(m0.min(), m1.min()), max(m0.max(), m1.max()))
+        h0, edges = np.histogram(m0, bins=50, range=rng_, density=True)
+        h1, _ = np.histogram(m1, bins=50, range=rng_, density=True)
+        centres = (edges[:-1] + edges[1:]) / 2
+        ok = (h0 > 0) & (h1 > 0)
+        want = curve_fit(lambda x, a: a * x, centres[ok], np.log(h0[ok] / h1[ok]))[0][0]
+        c0, _ = np.histogram(m0, bins=50, range=rng_)
+        c1, _ = np.histogram(m1, bins=50, range=rng_)
+        got = alvarado.alpha_from_histograms(edges, c0, c1)
+        assert got == pytest.approx(want, rel=1e-9)

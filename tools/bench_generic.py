@@ -49,8 +49,11 @@ for name, H, B in (("[[288,12,18]]", H288, 65536), ("space-time 864x2592", space
     dec = bp.decoder_for(csr_matrix(H))
     st = torch.cuda.current_stream(dev)
     out[name] = {"batch": B, "m": mm, "n": n, "edges": int(H.sum())}
-    for kname, k in (("general", _lib.KERNEL_GENERAL), ("stream", _lib.KERNEL_STREAM)):
+    for kname, k in (("onchip", _lib.KERNEL_ON_CHIP), ("general", _lib.KERNEL_GENERAL),
+                     ("stream", _lib.KERNEL_STREAM)):
         if kname not in args.kernels:
+            continue
+        if kname == "onchip" and (mm > 1024 or H.sum(1).max() > 8 or H.sum(0).max() > 4):
             continue
         dec.set_option(_lib.OPT_KERNEL, k)
 

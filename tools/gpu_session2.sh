@@ -11,7 +11,7 @@ for S in $STEPS; do
 case $S in
   pytest) echo "== pytest"; timeout -k 10 1000 python -m pytest tests -m gpu -q -s -x > $OUT/pytest.log 2>&1; echo "pytest exit=$?" | tee -a $OUT/pytest.log; tail -n 15 $OUT/pytest.log ;;
   pytestall) echo "== pytest (no -x)"; timeout -k 10 1100 python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1; echo "pytest exit=$?" | tee -a $OUT/pytest.log; tail -n 25 $OUT/pytest.log ;;
-  generic) echo "== generic"; timeout -k 10 300 python tools/bench_generic.py --kernels general > $OUT/generic.json 2> $OUT/generic.err; cat $OUT/generic.json; tail -n 3 $OUT/generic.err ;;
+  generic) echo "== generic"; timeout -k 10 300 python tools/bench_generic.py --kernels onchip general > $OUT/generic.json 2> $OUT/generic.err; cat $OUT/generic.json; tail -n 3 $OUT/generic.err ;;
   bench) echo "== bench"; timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit=$?"; cat $OUT/bench.json; tail -n 5 $OUT/bench.err ;;
   kernels) echo "== kernels"; (timeout -k 10 300 python tools/bench_osd.py; timeout -k 10 300 python tools/ab_early.py; timeout -k 10 300 python tools/measure_latency.py; timeout -k 10 300 python tools/bench_configs.py) > $OUT/kernels.log 2>&1; grep -v amdgpu.ids $OUT/kernels.log ;;
   fuzzmc) echo "== fuzz MC 16000"; QBP_FUZZ_CASES=16000 QBP_FUZZ_SEED=99991 timeout -k 10 1100 python -m pytest tests/test_gpu_fuzz.py -q -s -k "monte or mc" > $OUT/fuzz_mc.log 2>&1; echo "fuzz exit=$?"; tail -n 8 $OUT/fuzz_mc.log ;;
