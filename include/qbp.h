@@ -155,8 +155,10 @@ int qbp_message_histograms(qbp_handle* h, const uint8_t* syndromes, const uint8_
  *   [8] logical_error among not_converged  [9] detection == error exactly
  *   [10] OSD outputs that miss the syndrome (always 0)  [11] reserved (0).
  * Any matrix: those that fit the on-chip kernel (m <= 1024, row weight <= 8, column weight <= 4) run
- * the fused loop, all others the Monte-Carlo mode of the general-H kernel; QBP_FLAG_OSD0 needs the
- * on-chip kernel and 64 KiB of LDS for OSD-0 (QBP_E_UNSUPPORTED otherwise).
+ * the fused loop, all others the Monte-Carlo mode of the general-H kernel; QBP_FLAG_OSD0 works with
+ * both (matrices whose bit-packed rows exceed 64 KiB of LDS go through the workgroup-per-syndrome
+ * OSD kernel, whose matrix copy lives in global memory).  With QBP_FLAG_OSD0 a call keeps per-trial
+ * records (m + 10 n bytes each): at most QBP_MC_OSD_MAX_TRIALS trials and 16 GiB per call.
  */
 #define QBP_NUM_COUNTERS 12
 int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, double p,
@@ -174,7 +176,7 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
 
 /*
  * OSD-0 post-processing of B decoder outputs: decoding/OSD.py:3-28 performOSD (= OSD_enhanced.py
- * with order 0).  syndromes [B][m], llr [B][n], hard [B][n] -> solution [B][n].  Columns are
+ * with order 0), any matrix size.  syndromes [B][m], llr [B][n], hard [B][n] -> solution [B][n].  Columns are
  * ordered by ascending |llr|; equal values by ascending column index (np.argsort's order of
  * equal keys is unspecified in the reference).
  */
@@ -196,6 +198,9 @@ enum {
     QBP_OPT_KERNEL = 5,          /* 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome),
                                     3 streaming (lane per syndrome, messages in HBM)          */
     QBP_OPT_GENERAL_THREADS = 6, /* general-H kernel: threads per workgroup (0 = auto)        */
+    QBP_OPT_GENERAL_NO_LDS_TABLES = 8, /* 1 = general-H kernel reads its variable-step tables from L2 (A/B) */
+    QBP_OPT_OSD_BIG = 7,         /* 1 = OSD-0 through the workgroup-per-syndrome kernel (matrix in
+                                    global memory) even where the one-wavefront kernel fits (tests) */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
     QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 on-chip, 2 general-H, 3 streaming */
     QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109,

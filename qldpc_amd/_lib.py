@@ -24,7 +24,7 @@ NUM_COUNTERS = 12
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
                  "degenerateErrors", "not_converged", "sum_iterations",
                  "logical_error_not_converged", "exact_recoveries", "osd_invalid", "reserved1")
-OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_FORCE_GENERIC, OPT_KERNEL, OPT_GENERAL_THREADS = 1, 2, 4, 5, 6
+OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_FORCE_GENERIC, OPT_KERNEL, OPT_GENERAL_THREADS, OPT_OSD_BIG, OPT_GENERAL_NO_LDS_TABLES = 1, 2, 4, 5, 6, 7, 8
 KERNEL_AUTO, KERNEL_ON_CHIP, KERNEL_GENERAL, KERNEL_STREAM = 0, 1, 2, 3
 INFO = dict(m=100, n=101, edges=102, max_row_deg=103, max_col_deg=104, kernel_kind=105,
             threads=106, lds_bytes=107, grid=108, num_cu=109, last_kernel=110)
@@ -175,6 +175,10 @@ class Decoder:
             float(damping), float(clip_llr), int(flags), d_hard or None, d_converged or None,
             d_iters or None, d_llr or None, stream or None))
 
+    def mc_osd_step(self):
+        """Trials one qbp_mc_run call may cover with FLAG_OSD0 (per-trial records: m + 10 n bytes)."""
+        return max(1, min(MC_OSD_MAX_TRIALS, (8 << 30) // (self.m + 10 * self.n)))
+
     def mc_run(self, Lx, distance, p, prior, trial_begin, trial_end, draws=1, seed=0, max_iter=50,
                variant=SUM_PRODUCT, alpha=1.0, damping=1.0, clip_llr=20.0, flags=0):
         Lx = np.ascontiguousarray(Lx, np.uint8)
@@ -185,7 +189,7 @@ class Decoder:
             raise ValueError(f"prior must have shape ({self.n},)")
         counters = np.zeros(NUM_COUNTERS, np.int64)
         # with OSD a call keeps per-trial records on the device: split long ranges
-        step = MC_OSD_MAX_TRIALS if (int(flags) & FLAG_OSD0) else max(int(trial_end) - int(trial_begin), 1)
+        step = self.mc_osd_step() if (int(flags) & FLAG_OSD0) else max(int(trial_end) - int(trial_begin), 1)
         for a in range(int(trial_begin), int(trial_end), step):
             _check(load().qbp_mc_run(self._h, Lx.ctypes.data, Lx.shape[0], int(distance), float(p),
                                      int(draws), int(seed), a, min(a + step, int(trial_end)),

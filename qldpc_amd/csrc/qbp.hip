@@ -133,6 +133,7 @@ struct qbp_handle {
     int gcol_base[qbp::GENERIC_MAX_COL_CLASS + 2] = {0};
     int rpad_off[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0}, cpad_off[qbp::GENERIC_MAX_COL_CLASS + 2] = {0};
     int opt_threads = 0;            // general-H kernel: threads per workgroup (0 = auto)
+    int opt_no_lds_tables = 0;      // general-H kernel: keep the variable step's tables in L2 (A/B)
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
@@ -146,8 +147,13 @@ struct qbp_handle {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
     // OSD-0
-    bool osd_ok = false;
+    bool osd_ok = false;            // fits the one-wavefront kernel (matrix rows in LDS)
+    bool osd_big_ready = false;     // tables of the workgroup-per-syndrome kernel built (lazily)
     int osd_W = 0, osd_NP = 0, osd_lds = 0, osd_rank = 0;
+    DevBuf<uint32_t> d_osd_At;
+    DevBuf<int32_t> d_osd_piv, d_osd_idx;
+    DevBuf<uint8_t> d_osd_sol;
+    DevBuf<unsigned long long> d_osd_keys;
     DevBuf<uint32_t> d_hbits;
     DevBuf<int32_t> d_row_ptr, d_col_idx;
     DevBuf<uint8_t> d_sol;
@@ -471,14 +477,18 @@ static hipError_t generic_launch_v(int variant, const qbp::GenericParams& G, int
 //   threads per workgroup: the checks of weight <= 8 in as few, as full passes as possible
 //   (864 checks: 896 threads, one pass; 2592: 896 threads, three passes), at most 1024;
 //   workgroups per CU: as many as fit 16 wavefronts (the kernel's 128-register budget) and the LDS.
-struct GenericGeom { bool lds_msgs; int threads, per_cu, grid; size_t lds; };
+struct GenericGeom { bool lds_msgs, lds_tables; int threads, per_cu, grid; size_t lds; };
 
 static GenericGeom generic_geometry(const qbp_handle* h, long long B)
 {
     GenericGeom g{};
-    const size_t lds_full = qbp::generic_lds_bytes(h->m, std::max(h->E, 1), true);
-    g.lds_msgs = lds_full <= (size_t)160 * 1024;
-    g.lds = g.lds_msgs ? lds_full : qbp::generic_lds_bytes(h->m, std::max(h->E, 1), false);
+    const int E1 = std::max(h->E, 1);
+    constexpr size_t LDS_MAX = (size_t)160 * 1024;
+    g.lds_msgs = qbp::generic_lds_bytes(h->m, E1, h->n, true, false) <= LDS_MAX;
+    // the variable step's tables (prior, message positions) in LDS too when one workgroup per CU is
+    // the geometry anyway and they fit beside (or instead of) the messages
+    g.lds_tables = false;
+    g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, false);
     const int short_rows = std::max(1, h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 1] - h->row_off[1]);
     const int work = std::max(h->rpad_off[qbp::GENERIC_MAX_ROW_CLASS + 1], 64);    // padded work items
     const int passes = (work + 1023) / 1024;
@@ -492,8 +502,17 @@ static GenericGeom generic_geometry(const qbp_handle* h, long long B)
         const int wide = std::max(std::max(short_rows, h->n / 2), 64);
         threads = std::min(1024, (wide + 63) / 64 * 64);
     }
+    // messages in global memory: the variable step is bound by L2 / Infinity-Cache traffic, and more
+    // threads per syndrome is what puts more of it in flight (2592 x 7776: 1.89e5 syndromes/s with 1024
+    // threads against 1.72e5 with 896, the check step's exact fit)
+    if (!g.lds_msgs && B >= (long long)h->num_cu) threads = 1024;
     if (h->opt_threads > 0) threads = std::min(1024, (h->opt_threads + 63) / 64 * 64);
     if (h->opt_blocks_per_cu > 0) per_cu = h->opt_blocks_per_cu;
+    if (per_cu == 1 && !h->opt_no_lds_tables &&
+        qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true) <= LDS_MAX) {
+        g.lds_tables = true;
+        g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true);
+    }
     g.threads = threads; g.per_cu = per_cu;
     g.grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * per_cu));
     return g;
@@ -539,6 +558,7 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     std::copy(std::begin(h->rpad_off), std::end(h->rpad_off), G.rpad_off);
     std::copy(std::begin(h->cpad_off), std::end(h->cpad_off), G.cpad_off);
     G.prior_sorted = h->d_prior_sorted.p;
+    G.lds_tables = g.lds_tables ? 1 : 0;
     G.syndromes = d_syndromes; G.B = B; G.max_iter = max_iter; G.flags = flags;
     G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
     G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
@@ -732,6 +752,8 @@ void qbp_destroy(qbp_handle* h)
     h->d_epos.release(); h->d_cpos.release(); h->d_long_edge_row.release(); h->d_wsL.release();
     h->d_vpos.release(); h->d_vrow.release(); h->d_lcol_ptr.release(); h->d_prior_sorted.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
+    h->d_osd_At.release(); h->d_osd_piv.release(); h->d_osd_idx.release(); h->d_osd_sol.release();
+    h->d_osd_keys.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
     delete h;
@@ -1085,12 +1107,79 @@ static unsigned mc_threshold(double p)
     return (unsigned)t;
 }
 
+// Rank of H over GF(2) and its bit-packed rows for matrices beyond the one-wavefront kernel: built on
+// first use (64-bit Gaussian elimination on the host: about half a second for 2592 x 7776), not in
+// qbp_create, which most users of such matrices never follow with an OSD call.
+static int osd_big_prepare(qbp_handle* h)
+{
+    if (h->osd_big_ready) return QBP_OK;
+    const int m = h->m, n = h->n, W = h->osd_W;
+    std::vector<uint32_t> hbits((size_t)m * W, 0u);
+    for (int c = 0; c < m; ++c)
+        for (int e = h->row_ptr[c]; e < h->row_ptr[c + 1]; ++e)
+            hbits[(size_t)c * W + (h->col_idx[e] >> 5)] |= 1u << (h->col_idx[e] & 31);
+    HIP_TRY(h->d_hbits.reserve(hbits.size()));
+    HIP_TRY(hipMemcpy(h->d_hbits.p, hbits.data(), hbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const int W64 = (n + 63) / 64;
+    std::vector<uint64_t> A((size_t)m * W64, 0ull);
+    for (int c = 0; c < m; ++c)
+        for (int e = h->row_ptr[c]; e < h->row_ptr[c + 1]; ++e)
+            A[(size_t)c * W64 + (h->col_idx[e] >> 6)] |= 1ull << (h->col_idx[e] & 63);
+    int rank = 0;
+    for (int col = 0; col < n && rank < m; ++col) {
+        const int wi = col >> 6;
+        const uint64_t bit = 1ull << (col & 63);
+        int piv = -1;
+        for (int r = rank; r < m; ++r) if (A[(size_t)r * W64 + wi] & bit) { piv = r; break; }
+        if (piv < 0) continue;
+        if (piv != rank) for (int w = 0; w < W64; ++w) std::swap(A[(size_t)piv * W64 + w], A[(size_t)rank * W64 + w]);
+        for (int r = rank + 1; r < m; ++r)
+            if (A[(size_t)r * W64 + wi] & bit)
+                for (int w = wi; w < W64; ++w) A[(size_t)r * W64 + w] ^= A[(size_t)rank * W64 + w];
+        ++rank;
+    }
+    h->osd_rank = rank;
+    h->osd_big_ready = true;
+    return QBP_OK;
+}
+
 static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hipStream_t s)
 {
-    if (!h->osd_ok)
-        return fail(QBP_E_UNSUPPORTED, "OSD-0 needs %d B of LDS for this H (limit 64 KiB)", h->osd_lds);
-    O.m = h->m; O.n = h->n; O.W = h->osd_W; O.NP = h->osd_NP; O.rank = h->osd_rank;
-    O.hbits = h->d_hbits.p; O.row_ptr = h->d_row_ptr.p; O.col_idx = h->d_col_idx.p;
+    O.m = h->m; O.n = h->n; O.W = h->osd_W; O.NP = h->osd_NP;
+    O.row_ptr = h->d_row_ptr.p; O.col_idx = h->d_col_idx.p;
+    if (!h->osd_ok) {
+        // matrices whose rows do not fit 64 KiB of LDS: one workgroup per syndrome, working copy of
+        // [H | s] in a global workspace (qbp_osd.hpp, osd0_big_kernel)
+        int rc = osd_big_prepare(h);
+        if (rc) return rc;
+        O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
+        const size_t m = h->m, n = h->n, RS = (size_t)h->osd_W + 1, NP = (size_t)h->osd_NP;
+        const int grid = (int)std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 2));
+        qbp::OsdBigWorkspace Wk{};
+        Wk.keys_in_lds = NP * 12 <= (size_t)96 * 1024 ? 1 : 0;
+        HIP_TRY(h->d_osd_At.reserve((size_t)grid * RS * m));
+        HIP_TRY(h->d_osd_piv.reserve((size_t)grid * m));
+        HIP_TRY(h->d_osd_sol.reserve((size_t)grid * n));
+        if (!Wk.keys_in_lds) {
+            HIP_TRY(h->d_osd_keys.reserve((size_t)grid * NP));
+            HIP_TRY(h->d_osd_idx.reserve((size_t)grid * NP));
+        }
+        Wk.At = h->d_osd_At.p; Wk.pivcol = h->d_osd_piv.p; Wk.sol = h->d_osd_sol.p;
+        Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
+        const size_t lds = Wk.keys_in_lds ? NP * 12 : 0;
+        static thread_local size_t lds_set[64] = {0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (lds > 0 && (dev < 0 || dev >= 64 || lds_set[dev] < lds)) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qbp::osd0_big_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) lds_set[dev] = lds;
+        }
+        hipLaunchKernelGGL(qbp::osd0_big_kernel, dim3((unsigned)grid), dim3(256), lds, s, O, Wk);
+        HIP_TRY(hipGetLastError());
+        return QBP_OK;
+    }
+    O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
     const long long grid = std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 32));
     // row width (32-bit words incl. the syndrome word) as a template argument for the codes of the
     // reference: n = 72 / 90 / 108 -> 4 or 5, 144 -> 6, 288 -> 10
@@ -1163,18 +1252,49 @@ try {
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = mc_prepare(h, Lx_host, k, s);
     if (rc) return rc;
+    const bool osd = (flags & QBP_FLAG_OSD0) != 0;
+    if (osd) {
+        // per-trial records of the trials BP leaves unconverged (read by the OSD kernel)
+        const size_t t = (size_t)T, m = h->m, n = h->n;
+        if (T > QBP_MC_OSD_MAX_TRIALS || t * (m + 10 * n) > ((size_t)16 << 30))
+            return fail(QBP_E_INVALID, "with QBP_FLAG_OSD0 a call covers at most %lld trials of this matrix "
+                                       "(got %lld); split the range",
+                        (long long)std::min<size_t>(QBP_MC_OSD_MAX_TRIALS, ((size_t)16 << 30) / (m + 10 * n)),
+                        (long long)T);
+        HIP_TRY(h->d_fail_list.reserve(t));
+        HIP_TRY(h->d_fail_syn.reserve(t * m));
+        HIP_TRY(h->d_fail_llr.reserve(t * n));
+        HIP_TRY(h->d_fail_hard.reserve(t * n));
+        HIP_TRY(h->d_fail_err.reserve(t * n));
+        HIP_TRY(hipMemsetAsync(h->d_fail_count.p, 0, sizeof(unsigned long long), s));
+    }
+    auto osd_pass = [&]() -> int {
+        // second kernel: OSD-0 + classification of the trials BP left unconverged; their number is
+        // read from device memory by the kernel itself (no host round trip)
+        qbp::OsdParams O{};
+        O.count_ptr = reinterpret_cast<const long long*>(h->d_fail_count.p);
+        O.list = h->d_fail_list.p;
+        O.syndromes = h->d_fail_syn.p; O.llr = h->d_fail_llr.p; O.hard = h->d_fail_hard.p;
+        O.errors = h->d_fail_err.p; O.lx_cols = h->d_lx_cols.p; O.half_distance = distance / 2;
+        O.counters = reinterpret_cast<long long*>(d_counters);
+        return osd_launch(h, O, T, s);
+    };
     if (!h->fused_ok || h->opt_kernel == 2 || h->opt_force_generic) {
-        // matrices beyond the on-chip kernel: the whole loop inside the general-H kernel (BP only)
-        if (flags & QBP_FLAG_OSD0)
-            return fail(QBP_E_UNSUPPORTED, "QBP_FLAG_OSD0 needs a matrix that fits the on-chip kernel "
-                                           "(m <= 1024, row weight <= 8, column weight <= 4)");
+        // matrices beyond the on-chip kernel: the whole loop inside the general-H kernel
         qbp::GenericParams M{};
         M.lx_cols = h->d_lx_cols.p; M.trial_begin = trial_begin; M.seed = seed;
         M.threshold = mc_threshold(p); M.draws = draws; M.half_distance = distance / 2;
         M.counters = reinterpret_cast<long long*>(d_counters);
+        if (osd) {
+            M.fail_list = h->d_fail_list.p; M.fail_count = h->d_fail_count.p;
+            M.fail_syn = h->d_fail_syn.p; M.fail_llr = h->d_fail_llr.p;
+            M.fail_hard = h->d_fail_hard.p; M.fail_err = h->d_fail_err.p;
+        }
         h->last_kernel = 2;
-        return generic_launch(h, nullptr, d_prior, T, max_iter, variant, alpha, damping, clip_llr, flags,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0, s, &M);
+        rc = generic_launch(h, nullptr, d_prior, T, max_iter, variant, alpha, damping, clip_llr, flags,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0, s, &M);
+        if (rc) return rc;
+        return osd ? osd_pass() : QBP_OK;
     }
     LaunchCfg cfg;
     rc = make_cfg(h, T, &cfg);
@@ -1186,19 +1306,7 @@ try {
     P.lx_cols = h->d_lx_cols.p; P.trial_begin = trial_begin; P.seed = seed;
     P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = distance / 2;
     P.counters = reinterpret_cast<long long*>(d_counters);
-    const bool osd = (flags & QBP_FLAG_OSD0) != 0;
     if (osd) {
-        if (!h->osd_ok) return fail(QBP_E_UNSUPPORTED, "OSD-0 not available for this H");
-        if (T > QBP_MC_OSD_MAX_TRIALS)
-            return fail(QBP_E_INVALID, "with QBP_FLAG_OSD0 a call covers at most %d trials (got %lld); "
-                                       "split the range", QBP_MC_OSD_MAX_TRIALS, (long long)T);
-        const size_t t = (size_t)T, m = h->m, n = h->n;
-        HIP_TRY(h->d_fail_list.reserve(t));
-        HIP_TRY(h->d_fail_syn.reserve(t * m));
-        HIP_TRY(h->d_fail_llr.reserve(t * n));
-        HIP_TRY(h->d_fail_hard.reserve(t * n));
-        HIP_TRY(h->d_fail_err.reserve(t * n));
-        HIP_TRY(hipMemsetAsync(h->d_fail_count.p, 0, sizeof(unsigned long long), s));
         P.fail_list = h->d_fail_list.p; P.fail_count = h->d_fail_count.p;
         P.fail_syn = h->d_fail_syn.p; P.fail_llr = h->d_fail_llr.p;
         P.fail_hard = h->d_fail_hard.p; P.fail_err = h->d_fail_err.p;
@@ -1207,15 +1315,7 @@ try {
     HIP_TRY(launch_variant<true>(variant, P, cfg, s));
     h->last_kernel = 1;
     if (osd) {
-        // second kernel: OSD-0 + classification of the trials BP left unconverged; their number is
-        // read from device memory by the kernel itself (no host round trip)
-        qbp::OsdParams O{};
-        O.count_ptr = reinterpret_cast<const long long*>(h->d_fail_count.p);
-        O.list = h->d_fail_list.p;
-        O.syndromes = h->d_fail_syn.p; O.llr = h->d_fail_llr.p; O.hard = h->d_fail_hard.p;
-        O.errors = h->d_fail_err.p; O.lx_cols = h->d_lx_cols.p; O.half_distance = distance / 2;
-        O.counters = reinterpret_cast<long long*>(d_counters);
-        rc = osd_launch(h, O, T, s);
+        rc = osd_pass();
         if (rc) return rc;
     }
     return QBP_OK;
@@ -1302,6 +1402,16 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_KERNEL:
             if (value < 0 || value > 3) return fail(QBP_E_INVALID, "kernel selector out of range");
             h->opt_kernel = (int)value; return QBP_OK;
+        case QBP_OPT_OSD_BIG:
+            if (value != 0) { h->osd_ok = false; }
+            else {
+                const size_t lds = (size_t)h->osd_NP * 12 + (size_t)h->m * (h->osd_W + 1) * 4 + (size_t)h->m * 4 + (size_t)h->n + 16;
+                h->osd_ok = lds <= 64 * 1024 && h->m <= 64 * 32;
+                h->osd_big_ready = false;       // (osd_rank / d_hbits are shared: rebuild on next use)
+            }
+            return QBP_OK;
+        case QBP_OPT_GENERAL_NO_LDS_TABLES:
+            h->opt_no_lds_tables = value != 0; return QBP_OK;
         case QBP_OPT_GENERAL_THREADS:
             if (value < 0 || value > 1024) return fail(QBP_E_INVALID, "threads per workgroup out of range");
             h->opt_threads = (int)value; return QBP_OK;

@@ -74,6 +74,8 @@ struct GenericParams {
     int col_base[GENERIC_MAX_COL_CLASS + 2];
     int cpad_off[GENERIC_MAX_COL_CLASS + 2];   // work items of the variable step, padded like rpad_off
     const double* prior_sorted; // [n] prior of the sorted variable x (permuted once per call)
+    int lds_tables;             // 1: every workgroup keeps its own copy of vpos and prior_sorted in LDS
+                                // (read once per kernel instead of once per iteration from L2)
     // ---- the call ---------------------------------------------------------------------------------
     const uint8_t* syndromes;
     long long B;
@@ -113,12 +115,17 @@ struct GenericParams {
     uint8_t* fail_err;                  // [B][n]
 };
 
-// Dynamic LDS of one workgroup: messages (LDSMSG) + syndrome bits + two parity buffers + counters.
-__host__ __device__ inline size_t generic_lds_bytes(int m, int E, bool lds_msgs)
+// Dynamic LDS of one workgroup: messages (LDSMSG) + syndrome bits + two parity buffers + counters
+// (an even number of 32-bit words) + optional tables (prior_sorted [n] doubles, vpos [E] ints).
+__host__ __device__ inline size_t generic_lds_words(int m)
 {
     const size_t mw = ((size_t)m + 31) >> 5;
-    const size_t words = ((3 * mw + 2 + 1) & ~(size_t)1) + 4 + NUM_COUNTERS;
-    return (lds_msgs ? (size_t)16 * (size_t)E : 0) + words * 4;
+    return (((3 * mw + 2 + 1) & ~(size_t)1) + 4 + NUM_COUNTERS + 1) & ~(size_t)1;
+}
+__host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool lds_msgs, bool lds_tables)
+{
+    return (lds_msgs ? (size_t)16 * (size_t)E : 0) + generic_lds_words(m) * 4 +
+           (lds_tables ? (size_t)8 * (size_t)n + (size_t)4 * (size_t)E : 0);
 }
 
 // Check update of one row held in registers: q[D] -> r[D]   (beliefPropagation.py:114-126 /
@@ -251,6 +258,17 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
     int* const mc_weight = reinterpret_cast<int*>(words + acc_off + 2);
     int* const mc_diff = mc_weight + 1;
     int* const mc_cnt = mc_diff + 1;                // [NUM_COUNTERS] this workgroup's counter row (MC)
+    // tables of the variable step: from LDS when the launch reserved room for them, else from L2
+    const double* prior_t = P.prior_sorted;
+    const int32_t* vpos_t = P.vpos;
+    if (P.lds_tables) {
+        double* const pt = reinterpret_cast<double*>(words + generic_lds_words(m));
+        int32_t* const vt = reinterpret_cast<int32_t*>(pt + n);
+        for (int i = tid; i < n; i += nt) pt[i] = P.prior_sorted[i];
+        for (int i = tid; i < E; i += nt) vt[i] = P.vpos[i];
+        prior_t = pt; vpos_t = vt;
+        __syncthreads();
+    }
 
     const bool force_full = (P.flags & 1u) != 0;
     const bool pairwise = (P.flags & 4u) != 0;
@@ -319,13 +337,13 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         for (int x = tid + P.col_off[1]; x < first_lcol; x += nt) {
             int D, cnt, o;
             generic_col_class(P, x, D, cnt, o);
-            const int32_t* const pos = P.vpos + o;
-            const double pv = P.prior_sorted[x];
+            const int32_t* const pos = vpos_t + o;
+            const double pv = prior_t[x];
             for (int j = 0; j < D; ++j) Q[pos[(size_t)j * cnt]] = pv;
         }
         for (int i = tid; i < n_lcol; i += nt) {
-            const double pv = P.prior_sorted[first_lcol + i];
-            for (int k = P.lcol_ptr[i]; k < P.lcol_ptr[i + 1]; ++k) Q[P.vpos[k]] = pv;
+            const double pv = prior_t[first_lcol + i];
+            for (int k = P.lcol_ptr[i]; k < P.lcol_ptr[i + 1]; ++k) Q[vpos_t[k]] = pv;
         }
         __syncthreads();
         const int syn_weight = unsat[0];      // unsatisfied checks of the all-zero candidate
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         auto long_column_value = [&](int i, const int32_t*& pos, int& deg) {
             const int k0 = P.lcol_ptr[i];
             deg = P.lcol_ptr[i + 1] - k0;
-            pos = P.vpos + k0;
+            pos = vpos_t + k0;
             double s = 0.0;
             if (pairwise && deg >= 8) {
                 s = np_pairwise_gather<GENERIC_PAIRWISE_LEVELS>(R, pos, deg);
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                     s = (j == 0) ? r : s + r;                     // ascending check order
                 }
             }
-            return s + P.prior_sorted[first_lcol + i];
+            return s + prior_t[first_lcol + i];
         };
 
         // Outputs of this syndrome from the current R (values, hard decisions): decode mode writes
@@ -357,17 +375,17 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             for (int x = tid; x < n; x += nt) {
                 double val;
                 if (x < P.col_off[1]) {
-                    val = P.prior_sorted[x];                        // isolated variable
+                    val = prior_t[x];                        // isolated variable
                 } else if (x < first_lcol) {
                     int D, cnt, o;
                     generic_col_class(P, x, D, cnt, o);
-                    const int32_t* const pos = P.vpos + o;
+                    const int32_t* const pos = vpos_t + o;
                     double s = 0.0;
                     for (int j = 0; j < D; ++j) {
                         const double r = R[pos[(size_t)j * cnt]];
                         s = (j == 0) ? r : s + r;
                     }
-                    val = s + P.prior_sorted[x];
+                    val = s + prior_t[x];
                 } else {
                     const int32_t* pos; int deg;
                     val = long_column_value(x - first_lcol, pos, deg);
@@ -419,6 +437,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         for (int it = 0; it < P.max_iter; ++it) {
             const bool scale = !(P.dump_R != nullptr && it == P.dump_iter);
             // ================= check step =======================================================
+#ifndef QBP_GEN_SKIP_CHECK      /* (timing-only builds: tools/build_variants.sh) */
             for (int wp0 = tid - lane; wp0 < P.rpad_off[RC + 1]; wp0 += nt) {
                 // one wavefront = 64 consecutive work items of ONE weight class (scalar class search)
                 const int wpu = __builtin_amdgcn_readfirstlane(wp0);
@@ -450,6 +469,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 }
 #undef QBP_ROW_CLASS
             }
+#endif
             // ---- checks of weight > 8: the per-edge work (tanh; division + atanh) one thread per
             //      edge, the sequential part (np.prod in ascending column order / argmin and second
             //      minimum) one thread per check, two more workgroup barriers in between
@@ -535,6 +555,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 const unsigned old = atomicXor(&pbuf[cw >> 5], bit);
                 delta += (old & bit) ? -1 : 1;
             };
+#ifndef QBP_GEN_SKIP_VAR
             for (int xp0 = tid - lane; xp0 < P.cpad_off[CC + 1]; xp0 += nt) {
                 const int xpu = __builtin_amdgcn_readfirstlane(xp0);
                 int D = 1;
@@ -550,11 +571,11 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const int base = P.col_base[DD] + i;                                       \
                         int o[DD];                                                                 \
                         double r[DD];                                                              \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = P.vpos[base + j * cnt]; \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = vpos_t[base + j * cnt]; \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = R[o[j]];             \
                         double s = r[0];                                                           \
                         _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];               \
-                        const double val = s + P.prior_sorted[P.col_off[DD] + i];                  \
+                        const double val = s + prior_t[P.col_off[DD] + i];                  \
                         if (!frozen && val < 0.0) {                                                \
                             _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(P.vrow[base + j * cnt]); \
                         }                                                                          \
@@ -567,11 +588,12 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 }
 #undef QBP_COL_CLASS
             }
+#endif
             for (int i = tid; i < n_lcol; i += nt) {
                 const int32_t* pos; int deg;
                 const double val = long_column_value(i, pos, deg);
                 if (!frozen && val < 0.0) {
-                    const int32_t* const row = P.vrow + (pos - P.vpos);
+                    const int32_t* const row = P.vrow + (pos - vpos_t);
                     for (int j = 0; j < deg; ++j) flip(row[j]);
                 }
                 for (int j = 0; j < deg; ++j) q_update(pos[j], val, R[pos[j]]);

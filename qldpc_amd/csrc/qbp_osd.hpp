@@ -200,4 +200,155 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// OSD-0 for matrices whose bit-packed rows do not fit the LDS of one wavefront's workgroup (space-time
+// and circuit-level matrices: 2592 x 7776 is 2.5 MB per syndrome).  One workgroup per syndrome; the
+// working copy of [H | residual syndrome] lives in a per-workgroup global workspace, stored TRANSPOSED
+// (word w of row r at At[w * m + r]) so that the threads of a wavefront -- one matrix row each -- read
+// and write consecutive addresses; sort keys in LDS when n <= 8192, else in the workspace too.
+// Same algorithm and tie rules as osd0_kernel above, hence the same solutions (tested on the small
+// codes, where both kernels apply).
+struct OsdBigWorkspace {
+    uint32_t* At;                   // [grid][(W + 1) * m]
+    int32_t* pivcol;                // [grid][m]
+    uint8_t* sol;                   // [grid][n]
+    unsigned long long* keys;       // [grid][NP]   (only when the keys do not fit LDS)
+    int32_t* idx;                   // [grid][NP]
+    int keys_in_lds;
+};
+
+__global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const OsdBigWorkspace Wk)
+{
+    extern __shared__ double osd_smem[];
+    __shared__ int s_piv;
+    __shared__ unsigned long long s_lm;
+    __shared__ int s_ew, s_df, s_bad;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int m = P.m, n = P.n, W = P.W, NP = P.NP, RS = P.W + 1;
+    unsigned long long* keys;
+    int* idx;
+    if (Wk.keys_in_lds) {
+        keys = reinterpret_cast<unsigned long long*>(osd_smem);
+        idx = reinterpret_cast<int*>(keys + NP);
+    } else {
+        keys = Wk.keys + (size_t)blockIdx.x * NP;
+        idx = Wk.idx + (size_t)blockIdx.x * NP;
+    }
+    uint32_t* const At = Wk.At + (size_t)blockIdx.x * RS * m;
+    int* const pivcol = Wk.pivcol + (size_t)blockIdx.x * m;
+    uint8_t* const sol = Wk.sol + (size_t)blockIdx.x * n;
+
+    const long long total = P.count_ptr ? *P.count_ptr : P.count;
+    for (long long item = blockIdx.x; item < total; item += gridDim.x) {
+        const long long rec = P.list ? P.list[item] : item;
+        const double* llr = P.llr + rec * n;
+        const uint8_t* hard = P.hard + rec * n;
+        const uint8_t* syn = P.syndromes + rec * m;
+        // ---- 1. ordering = argsort(|llr|), ties by column index                    OSD.py:10-11
+        for (int i = tid; i < NP; i += nt) {
+            keys[i] = i < n ? osd_order_key(llr[i]) : ~0ull;
+            idx[i] = i;
+        }
+        for (int i = tid; i < n; i += nt) sol[i] = hard[i] & 1u;
+        __syncthreads();
+        for (int k = 2; k <= NP; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < NP / 2; t += nt) {
+                    const int lo = ((t / j) * (2 * j)) + (t % j);
+                    const int hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const unsigned long long ka = keys[lo], kb = keys[hi];
+                    const int ia = idx[lo], ib = idx[hi];
+                    if (osd_less(kb, ib, ka, ia) == up) {
+                        keys[lo] = kb; keys[hi] = ka; idx[lo] = ib; idx[hi] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- 2. A = [H | residual syndrome]                                         OSD.py:7-8
+        for (int r = tid; r < m; r += nt) {
+            for (int w = 0; w < W; ++w) At[(size_t)w * m + r] = P.hbits[(size_t)r * W + w];
+            unsigned par = syn[r] & 1u;
+            for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) par ^= sol[P.col_idx[e]];
+            At[(size_t)W * m + r] = par;
+            pivcol[r] = -1;
+        }
+        __syncthreads();
+        // ---- 3. Gauss-Jordan over the columns in reliability order                  OSD.py:31-72
+        int rank = 0;
+        for (int k = 0; k < n && rank < P.rank; ++k) {
+            const int c = idx[k];
+            const uint32_t* const colw = At + (size_t)(c >> 5) * m;
+            const uint32_t bit = 1u << (c & 31);
+            if (tid == 0) s_piv = 0x7fffffff;
+            __syncthreads();
+            int mine = 0x7fffffff;
+            for (int r = tid; r < m; r += nt)
+                if ((colw[r] & bit) && pivcol[r] < 0) { mine = r; break; }     // this thread's first
+            if (mine != 0x7fffffff) atomicMin(&s_piv, mine);
+            __syncthreads();
+            const int p = s_piv;                      // the first unused row with a 1 (:46-50)
+            if (p == 0x7fffffff) continue;            // column depends on earlier ones (:52-53)
+            ++rank;
+            for (int r = tid; r < m; r += nt) {
+                if (r != p && (colw[r] & bit)) {
+                    // (the word holding bit c goes last: it is the loop's own condition for no one,
+                    // but rows are independent, so any order is fine; keep it simple)
+                    for (int w = 0; w <= W; ++w) At[(size_t)w * m + r] ^= At[(size_t)w * m + p];   // :63-68
+                }
+            }
+            if (tid == 0) pivcol[p] = c;
+            __syncthreads();
+        }
+        // ---- 4. e[pivot column] = reduced syndrome bit; solution = hard + e         OSD.py:14-26
+        for (int r = tid; r < m; r += nt) {
+            const int c = pivcol[r];
+            if (c >= 0 && (At[(size_t)W * m + r] & 1u)) sol[c] ^= 1u;   // distinct pivot columns: no race
+        }
+        if (tid == 0) { s_lm = 0ull; s_ew = 0; s_df = 0; s_bad = 0; }
+        __syncthreads();
+        if (P.solution)
+            for (int i = tid; i < n; i += nt) P.solution[rec * n + i] = sol[i];
+        if (P.errors) {
+            const uint8_t* err = P.errors + rec * n;
+            unsigned long long lm = 0ull;
+            int ew = 0;
+            unsigned df = 0, bad = 0;
+            for (int i = tid; i < n; i += nt) {
+                const unsigned e = err[i] & 1u;
+                const unsigned res = sol[i] ^ e;
+                ew += (int)e;
+                df |= res;
+                if (res) lm ^= P.lx_cols[i];
+            }
+            for (int r = tid; r < m; r += nt) {
+                unsigned par = syn[r] & 1u;
+                for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) par ^= sol[P.col_idx[e]];
+                bad |= par;
+            }
+            if (lm) atomicXor(&s_lm, lm);
+            if (ew) atomicAdd(&s_ew, ew);
+            if (df) atomicOr(&s_df, 1);
+            if (bad) atomicOr(&s_bad, 1);
+            __syncthreads();
+            if (tid == 0) {
+                auto add = [&](int i) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i), 1ull);
+                };
+                const bool logical = s_lm != 0ull;
+                if (!s_bad && !logical && s_df) add(5);
+                if (logical) {
+                    add(1);
+                    add(s_ew < P.half_distance ? 3 : 4);
+                    add(8);
+                }
+                if (!s_df) add(9);
+                if (s_bad) add(10);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace qbp

@@ -66,7 +66,7 @@ def run_sweep(code_name, ps, trials, *, draws=1, seed=0, max_iter=50, variant=_l
         stream = torch.cuda.current_stream(dev)
         priors = [torch.from_numpy(prior_of(p, code.n)).to(dev) for p in ps]
         flags = _lib.FLAG_OSD0 if osd else 0
-        step = _lib.MC_OSD_MAX_TRIALS if osd else 1 << 40    # OSD keeps per-trial records
+        step = dec.mc_osd_step() if osd else 1 << 40         # OSD keeps per-trial records
         for i, p in enumerate(ps):
             begin, end = shard_range(trials, rank, world)
             for a in range(begin, end, step):

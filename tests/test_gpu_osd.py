@@ -130,3 +130,87 @@ def test_config5_full_sweep_against_reference_tables():
     up = [ler[p] for p in sorted(p for p in ps if p >= 0.01)]
     assert all(a < b for a, b in zip(up, up[1:])), up
     assert ler[0.1] > 0.5
+
+
+def _fresh_decoder(H):
+    """A decoder of its own (options below must not leak into the shared cache)."""
+    row_ptr, col_idx, m, n = bp.csr_from_H(H)
+    return _lib.Decoder(row_ptr, col_idx, m, n, bp.DEVICE)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_big_osd_kernel_equals_reference_goldens(tag):
+    """The workgroup-per-syndrome OSD-0 kernel (matrix copy in global memory: the path of matrices whose
+    bit-packed rows exceed 64 KiB of LDS), forced onto the small codes: same solutions as the
+    reference's performOSD and as the one-wavefront kernel."""
+    c = load_osd(tag)
+    H = c["H"].astype(np.int64)
+    dec = _fresh_decoder(H)
+    small = dec.osd0(c["syndromes"], c["llr"], c["hard"])
+    dec.set_option(_lib.OPT_OSD_BIG, 1)
+    big = dec.osd0(c["syndromes"], c["llr"], c["hard"])
+    assert np.array_equal(big, c["solution"]) and np.array_equal(big, small)
+
+
+def test_osd_beyond_the_lds_limit():
+    """OSD-0 on a matrix only the big kernel takes (two copies of the 864 x 2592 space-time matrix of
+    [[144,12,12]]: m = 1728, rows of 5184 bits = 1.1 MB per syndrome): every solution reproduces its
+    syndrome, and the first one equals the oracle's (the oracle's dense elimination takes seconds on
+    this size, so only one is compared)."""
+    from scipy.sparse import block_diag, csr_matrix
+    H144 = codes.load_code("[[144, 12, 12]]").Hx
+    mm = H144.shape[0]
+    T = 12
+    st = np.hstack([np.kron(np.eye(T, dtype=np.int64), H144),
+                    (np.eye(mm * T, dtype=np.int64) + np.eye(mm * T, k=-mm, dtype=np.int64)) % 2])
+    H = block_diag([csr_matrix(st), csr_matrix(st)]).toarray().astype(np.int64)      # 1728 x 5184
+    dec = _fresh_decoder(csr_matrix(H))
+    assert dec.info("kernel_kind") == 2
+    rng = np.random.default_rng(5)
+    p = 0.03
+    n = H.shape[1]
+    err = (rng.random((40, n)) < p).astype(np.uint8)
+    syn = (err @ H.T % 2).astype(np.uint8)
+    hard, conv, iters, llr = dec.decode(syn, mc.prior_of(p, n), 12)
+    f = np.flatnonzero(~conv)[:8]
+    assert len(f) >= 3
+    got = dec.osd0(syn[f], llr[f], hard[f])
+    assert np.array_equal((got.astype(np.int64) @ H.T) % 2, syn[f])
+    assert np.array_equal(got[0], oracle.osd0(H, syn[f[0]], llr[f[0]], hard[f[0]]))
+    one = osd.performOSD(csr_matrix(H), syn[f[1]], llr[f[1]], hard[f[1]])
+    assert np.array_equal(one, got[1])
+
+
+def test_mc_osd_on_an_irregular_matrix_equals_oracle():
+    """BP + OSD-0 Monte-Carlo where the general-H kernel is the only BP kernel ([[72,12,6]] plus one
+    check of weight 12): counters equal the oracle pipeline's, with either OSD kernel."""
+    code = codes.load_code("[[72, 12, 6]]")
+    extra = np.zeros((1, code.n), np.int64); extra[0, ::6] = 1
+    H = np.vstack([code.Hx, extra])
+    p = 0.05
+    prior = mc.prior_of(p, code.n)
+    want = oracle.mc_counters(H, code.Lx, code.distance, p, prior, 0, 4000, seed=2, max_iter=20, osd=True)
+    for big in (0, 1):
+        dec = _fresh_decoder(H)
+        assert dec.info("kernel_kind") == 2
+        dec.set_option(_lib.OPT_OSD_BIG, big)
+        got = dec.mc_run(code.Lx, code.distance, p, prior, 0, 4000, seed=2, max_iter=20, flags=_lib.FLAG_OSD0)
+        print(big, dict(zip(_lib.COUNTER_NAMES, got.tolist())))
+        assert got[0] == want[0] == 4000 and got[6] == want[6] and got[7] == want[7] and got[10] == 0
+        assert np.abs(got - want).max() <= 3
+
+
+def test_mc_osd_general_kernel_equals_on_chip_kernel():
+    """BP + OSD-0 Monte-Carlo through the general-H kernel (forced) = through the on-chip kernel,
+    counter for counter: both produce the same BP outputs bit for bit, hence the same OSD inputs."""
+    code = codes.load_code("[[72, 12, 6]]")
+    p = 0.06
+    prior = mc.prior_of(p, code.n)
+    a = _fresh_decoder(code.Hx).mc_run(code.Lx, code.distance, p, prior, 3, 20003, seed=1, flags=_lib.FLAG_OSD0)
+    g = _fresh_decoder(code.Hx)
+    g.set_option(_lib.OPT_KERNEL, _lib.KERNEL_GENERAL)
+    b = g.mc_run(code.Lx, code.distance, p, prior, 3, 20003, seed=1, flags=_lib.FLAG_OSD0)
+    assert np.array_equal(a, b), (a, b)
+    g.set_option(_lib.OPT_OSD_BIG, 1)
+    c = g.mc_run(code.Lx, code.distance, p, prior, 3, 20003, seed=1, flags=_lib.FLAG_OSD0)
+    assert np.array_equal(a, c), (a, c)

@@ -253,7 +253,7 @@ def test_self_launch_command_and_supervisor(tmp_path):
         "from qldpc_amd import launch\n"
         "launch.maybe_self_launch(2, [os.path.abspath(__file__)])\n"
         "assert 'torch' not in sys.modules\n"
-        "print('rank', os.environ['RANK'], 'of', os.environ['WORLD_SIZE'], flush=True)\n"
+        "sys.stdout.write('rank %s of %s\\n' % (os.environ['RANK'], os.environ['WORLD_SIZE'])); sys.stdout.flush()\n"
         "sys.exit(7 if os.environ['RANK'] == '1' else 0)\n")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, timeout=300, env=env)

@@ -20,15 +20,16 @@
 
 namespace {
 
-constexpr int REP = 4000;       // loop iterations; 32 instructions each
+constexpr int REP = 1000;       // loop iterations; 128 instructions each
 
 enum { C_FMA, C_MUL, C_ADD, C_MINMAX, C_CMP, C_CVT, C_TRANS, C_B32, C_LANE, C_COUNT };
 const char* const NAMES[C_COUNT] = {"fma_f64", "mul_f64", "add_f64", "minmax_f64", "cmp_f64", "cvt_f64",
                                     "trans_f64", "alu_b32", "lane_b32"};
 
-// 8 independent chains x 4 = 32 instructions of the class per loop iteration
+// 8 independent chains x 16 = 128 instructions of the class per loop iteration
 #define X8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 #define X32(S) X8(S) X8(S) X8(S) X8(S)
+#define X128(S) X32(S) X32(S) X32(S) X32(S)
 
 template <int CLS>
 __global__ __launch_bounds__(1024) void rate_kernel(double* out, double seed, int rep, unsigned long long* cyc)
@@ -46,40 +47,40 @@ __global__ __launch_bounds__(1024) void rate_kernel(double* out, double seed, in
     for (int i = 0; i < rep; ++i) {
         if constexpr (CLS == C_FMA) {
 #define S(k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[k]) : "v"(c), "v"(d));
-            X32(S)
+            X128(S)
 #undef S
         } else if constexpr (CLS == C_MUL) {
 #define S(k) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[k]) : "v"(c));
-            X32(S)
+            X128(S)
 #undef S
         } else if constexpr (CLS == C_ADD) {
 #define S(k) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[k]) : "v"(d));
-            X32(S)
+            X128(S)
 #undef S
         } else if constexpr (CLS == C_MINMAX) {
 #define S(k) asm volatile("v_max_f64 %0, %0, %1" : "+v"(a[k]) : "v"(d));
-            X32(S)
+            X128(S)
 #undef S
         } else if constexpr (CLS == C_CMP) {
 #define S(k) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(a[k]), "v"(c) : "vcc");
-            X32(S)
+            X128(S)
 #undef S
         } else if constexpr (CLS == C_CVT) {
 #define S(k) asm volatile("v_rndne_f64 %0, %0" : "+v"(a[k]));
-            X32(S)
+            X128(S)
 #undef S
         } else if constexpr (CLS == C_TRANS) {
 #define S(k) asm volatile("v_rcp_f64 %0, %0" : "+v"(a[k]));
-            X32(S)
+            X128(S)
 #undef S
         } else if constexpr (CLS == C_B32) {
 #define S(k) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
-            X32(S)
+            X128(S)
 #undef S
         } else {
             unsigned s0;
 #define S(k) asm volatile("v_readlane_b32 %0, %1, 3\n\tv_writelane_b32 %1, %0, 5" : "=s"(s0), "+v"(u[k]));
-            X8(S) X8(S)          // 16 pairs = 32 instructions
+            X32(S) X32(S)        // 64 pairs = 128 instructions
 #undef S
         }
     }
@@ -203,7 +204,7 @@ int run_rate(int waves_per_simd, int num_cu, double* out, double* rate, double* 
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     const double waves = (double)blocks * (threads / 64);
-    *rate = waves * REP * 32.0 / (best * 1e-3);
+    *rate = waves * REP * 128.0 / (best * 1e-3);
     if (cycles_per_inst) {
         // shader-clock cycles one SIMD needs per wave-instruction of this class: every SIMD of a CU
         // hosts threads / 256 waves that each issue REP * 32 instructions while the block runs
@@ -220,7 +221,7 @@ int run_rate(int waves_per_simd, int num_cu, double* out, double* rate, double* 
             mean += (double)(hi - lo);
         }
         mean /= nb;
-        *cycles_per_inst = mean / ((threads / 256.0) * (double)REP * 32.0);
+        *cycles_per_inst = mean / ((threads / 256.0) * (double)REP * 128.0);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
