@@ -211,7 +211,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             if constexpr (PACK_NBR) {
                 if (k & 1) nbr[j][k / 2] |= o << 16; else nbr[j][k / 2] = o;
             } else {
-                nbr[j][k] = o;
+                nbr[j][k] = o;      // (the compiler keeps the 18 byte addresses in registers)
             }
         }
     }
@@ -383,17 +383,17 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 #pragma unroll
                     for (int k = 0; k < DV; ++k)
                         if (j0 + jj < DC) {
-                            unsigned o;
                             if constexpr (PACK_NBR) {
+                                unsigned o;
                                 // (opaque: otherwise the 32 unpacked byte addresses are hoisted out
                                 // of the iteration loop -- loop-invariant -- and spilled to scratch)
                                 unsigned pk = nbr[j0 + jj][k / 2];
                                 asm volatile("" : "+v"(pk));
                                 o = (k & 1) ? pk >> 16 : pk & 0xffffu;
+                                rr[jj][k] = Rs[o];
                             } else {
-                                o = nbr[j0 + jj][k];
+                                rr[jj][k] = Rs[nbr[j0 + jj][k]];
                             }
-                            rr[jj][k] = Rs[o];
                         }
                     if constexpr (!HOLD_R)
                         if (j0 + jj < DC) rown[jj] = Rs[(j0 + jj) * m + c];

@@ -63,3 +63,45 @@ for p in (0.002, 0.02):
     print(f"space-time 2592 x 7776, p={p}: Decoder.decode(B=1) {dt / len(syn) * 1e6:.0f} us per call, "
           f"mean {np.mean(its) + 1:.1f} iterations, kernel {dec.info('last_kernel')}, "
           f"{dec.info('threads')} threads")
+
+# the reference driver's batch call (paperResults_GPU.py:108: 5000 syndromes, maxIter 150), host
+# arrays in and out: where the time of one call goes
+code = codes.load_code("[[288, 12, 18]]")
+H = code.Hx
+n = code.n
+p = 0.05
+rng = np.random.default_rng(0)
+e = ((rng.random((5000, n)) < p) ^ (rng.random((5000, n)) < p)).astype(np.int64)
+syn = (e @ H.T % 2)
+prior = np.full(n, np.log((1 - p) / p))
+dec = bp.decoder_for(H)
+syn8 = syn.astype(np.uint8)
+dec.decode(syn8, prior, 150)                      # buffers of this size exist from here on
+t0 = time.perf_counter()
+for _ in range(5):
+    dec.decode(syn8, prior, 150)
+t_c = (time.perf_counter() - t0) / 5
+t0 = time.perf_counter()
+for _ in range(5):
+    dec.decode(syn8, prior, 150, want_llr=False)
+t_nollr = (time.perf_counter() - t0) / 5
+t0 = time.perf_counter()
+for _ in range(5):
+    bp.performBeliefPropagationBatch(H, syn, prior, maxIter=150)
+t_py = (time.perf_counter() - t0) / 5
+import torch  # noqa: E402
+dev = torch.device("cuda", 0)
+d_syn = torch.from_numpy(syn8).to(dev); d_pr = torch.from_numpy(prior).to(dev)
+d_hard = torch.empty((5000, n), dtype=torch.uint8, device=dev); d_conv = torch.empty(5000, dtype=torch.uint8, device=dev)
+d_it = torch.empty(5000, dtype=torch.int32, device=dev); d_llr = torch.empty((5000, n), dtype=torch.float64, device=dev)
+st = torch.cuda.current_stream(dev)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    dec.decode_device(d_syn.data_ptr(), d_pr.data_ptr(), 5000, 150, 0, 1.0, 1.0, 20.0, 0, d_hard.data_ptr(),
+                      d_conv.data_ptr(), d_it.data_ptr(), d_llr.data_ptr(), st.cuda_stream)
+torch.cuda.synchronize()
+t_k = (time.perf_counter() - t0) / 5
+print(f"[[288, 12, 18]] batch of 5000 (two draws at p = 0.05, maxIter 150): kernel alone {t_k * 1e3:.2f} ms; "
+      f"qbp_decode_batch (host arrays, 13 MB back) {t_c * 1e3:.2f} ms, without the LLR array {t_nollr * 1e3:.2f} ms; "
+      f"performBeliefPropagationBatch (Python mirror: casts, checks, int8 / bool views) {t_py * 1e3:.2f} ms")

@@ -13,7 +13,7 @@ G4="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_
 G5="TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum"
 for M in "864x2592" "2592x7776"; do
   i=0
-  for C in "$G1" "$G2" "$G3" "$G4" "FETCH_SIZE WRITE_SIZE" "GRBM_GUI_ACTIVE" "$G5"; do
+  for C in "$G1" "$G2" "$G3" "$G4" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
     i=$((i+1)); d=$OUT/pmc_${M}_$i
     timeout -k 10 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d -o pmc -- python3 $R/tools/bench_generic.py --kernels general --only $M --reps 1 > $d.log 2>&1
     echo "pmc $M pass $i exit=$?"
@@ -21,7 +21,7 @@ for M in "864x2592" "2592x7776"; do
 done
 # headline kernel: instruction mix by class
 i=0
-for C in "$G3" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES" "GRBM_GUI_ACTIVE"; do
+for C in "$G3" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); d=$OUT/pmc_fused_$i
   timeout -k 10 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --mode forced > $d.log 2>&1
   echo "pmc fused pass $i exit=$?"

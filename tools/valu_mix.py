@@ -121,7 +121,7 @@ def loop_mix(insts):
     """VALU instructions per execution of the main loop's always-executed part, by class."""
     # the main loop: of all backward branches, the one whose span holds the most FP64 arithmetic;
     # among equals the tightest (out-of-line cold blocks behind the loop jump back over it too)
-    addrs = [a for a, m, o, t in insts if m.startswith(("v_fma_f64", "v_fmac_f64", "v_rcp_f64", "v_mul_f64"))]
+    addrs = [a for a, m, o, t in insts if m.startswith("v_") and "_f64" in m]
     back = []
     for a, m, o, t in insts:
         if t is not None and t <= a:
@@ -131,8 +131,9 @@ def loop_mix(insts):
     _, _, lo, hi = max(back)
     body = [(a, m, o, t) for a, m, o, t in insts if lo <= a <= hi]
     # if-regions from forward conditional branches inside the loop: (start, end) half-open
-    regions = sorted((a, t) for a, m, o, t in body
-                     if t is not None and m.startswith("s_cbranch") and a < t <= hi + 4)
+    # (a branch to an out-of-line block behind the loop guards everything up to the loop's end)
+    regions = sorted((a, min(t, hi + 4)) for a, m, o, t in body
+                     if t is not None and m.startswith("s_cbranch") and a < t)
     # nesting by containment; direct coldness
     def innermost(addr):
         best = None
