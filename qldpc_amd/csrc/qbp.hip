@@ -134,6 +134,7 @@ struct qbp_handle {
     int rpad_off[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0}, cpad_off[qbp::GENERIC_MAX_COL_CLASS + 2] = {0};
     int opt_threads = 0;            // general-H kernel: threads per workgroup (0 = auto)
     int opt_no_lds_tables = 0;      // general-H kernel: keep the variable step's tables in L2 (A/B)
+    int opt_no_r_split = 0;         // general-H kernel: no part of R in LDS when the messages do not fit (A/B)
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
@@ -444,10 +445,10 @@ void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg)
 
 }  // namespace
 
-template <int VARIANT, bool MC, bool LDSMSG>
+template <int VARIANT, bool MC, int MEM>
 static hipError_t generic_launch_k(const qbp::GenericParams& G, int grid, int threads, size_t lds, hipStream_t s)
 {
-    auto kern = qbp::bp_generic_kernel<VARIANT, MC, LDSMSG>;
+    auto kern = qbp::bp_generic_kernel<VARIANT, MC, MEM>;
     static thread_local size_t lds_set[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -461,14 +462,25 @@ static hipError_t generic_launch_k(const qbp::GenericParams& G, int grid, int th
     return hipGetLastError();
 }
 
-template <bool MC, bool LDSMSG>
+template <bool MC, int MEM>
 static hipError_t generic_launch_v(int variant, const qbp::GenericParams& G, int grid, int threads, size_t lds,
                                    hipStream_t s)
 {
     switch (variant) {
-        case QBP_SUM_PRODUCT: return generic_launch_k<0, MC, LDSMSG>(G, grid, threads, lds, s);
-        case QBP_DAMPED_SP:   return generic_launch_k<1, MC, LDSMSG>(G, grid, threads, lds, s);
-        default:              return generic_launch_k<2, MC, LDSMSG>(G, grid, threads, lds, s);
+        case QBP_SUM_PRODUCT: return generic_launch_k<0, MC, MEM>(G, grid, threads, lds, s);
+        case QBP_DAMPED_SP:   return generic_launch_k<1, MC, MEM>(G, grid, threads, lds, s);
+        default:              return generic_launch_k<2, MC, MEM>(G, grid, threads, lds, s);
+    }
+}
+
+template <bool MC>
+static hipError_t generic_launch_m(int mem, int variant, const qbp::GenericParams& G, int grid, int threads,
+                                   size_t lds, hipStream_t s)
+{
+    switch (mem) {
+        case qbp::GENERIC_MEM_LDS:   return generic_launch_v<MC, qbp::GENERIC_MEM_LDS>(variant, G, grid, threads, lds, s);
+        case qbp::GENERIC_MEM_SPLIT: return generic_launch_v<MC, qbp::GENERIC_MEM_SPLIT>(variant, G, grid, threads, lds, s);
+        default:                     return generic_launch_v<MC, qbp::GENERIC_MEM_GLOBAL>(variant, G, grid, threads, lds, s);
     }
 }
 
@@ -477,7 +489,7 @@ static hipError_t generic_launch_v(int variant, const qbp::GenericParams& G, int
 //   threads per workgroup: the checks of weight <= 8 in as few, as full passes as possible
 //   (864 checks: 896 threads, one pass; 2592: 896 threads, three passes), at most 1024;
 //   workgroups per CU: as many as fit 16 wavefronts (the kernel's 128-register budget) and the LDS.
-struct GenericGeom { bool lds_msgs, lds_tables; int threads, per_cu, grid; size_t lds; };
+struct GenericGeom { bool lds_msgs, lds_tables; int mem, r_split, threads, per_cu, grid; size_t lds; };
 
 static GenericGeom generic_geometry(const qbp_handle* h, long long B)
 {
@@ -508,10 +520,19 @@ static GenericGeom generic_geometry(const qbp_handle* h, long long B)
     if (!g.lds_msgs && B >= (long long)h->num_cu) threads = 1024;
     if (h->opt_threads > 0) threads = std::min(1024, (h->opt_threads + 63) / 64 * 64);
     if (h->opt_blocks_per_cu > 0) per_cu = h->opt_blocks_per_cu;
+    g.mem = g.lds_msgs ? qbp::GENERIC_MEM_LDS : qbp::GENERIC_MEM_GLOBAL;
+    g.r_split = 0;
+    if (!g.lds_msgs && per_cu == 1 && !h->opt_no_r_split) {
+        // the messages do not fit: as much of R as the LDS holds (the rest, and Q, in the workspace)
+        const size_t room = LDS_MAX - qbp::generic_lds_bytes(h->m, E1, h->n, false, false);
+        const int K = (int)std::min<size_t>((size_t)E1, room / 8);
+        if (K >= E1 / 4) { g.mem = qbp::GENERIC_MEM_SPLIT; g.r_split = K; }
+        g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, false, false, g.r_split);
+    }
     if (per_cu == 1 && !h->opt_no_lds_tables &&
-        qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true) <= LDS_MAX) {
+        qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split) <= LDS_MAX) {
         g.lds_tables = true;
-        g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true);
+        g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split);
     }
     g.threads = threads; g.per_cu = per_cu;
     g.grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * per_cu));
@@ -559,6 +580,7 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     std::copy(std::begin(h->cpad_off), std::end(h->cpad_off), G.cpad_off);
     G.prior_sorted = h->d_prior_sorted.p;
     G.lds_tables = g.lds_tables ? 1 : 0;
+    G.r_split = g.r_split;
     G.syndromes = d_syndromes; G.B = B; G.max_iter = max_iter; G.flags = flags;
     G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
     G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
@@ -573,12 +595,10 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
         G.counters = mc->counters; G.wsE = h->d_wsE.p;
         G.fail_list = mc->fail_list; G.fail_count = mc->fail_count; G.fail_syn = mc->fail_syn;
         G.fail_llr = mc->fail_llr; G.fail_hard = mc->fail_hard; G.fail_err = mc->fail_err;
-        HIP_TRY(g.lds_msgs ? (generic_launch_v<true, true>(variant, G, g.grid, g.threads, g.lds, s))
-                           : (generic_launch_v<true, false>(variant, G, g.grid, g.threads, g.lds, s)));
+        HIP_TRY(generic_launch_m<true>(g.mem, variant, G, g.grid, g.threads, g.lds, s));
         return QBP_OK;
     }
-    HIP_TRY(g.lds_msgs ? (generic_launch_v<false, true>(variant, G, g.grid, g.threads, g.lds, s))
-                       : (generic_launch_v<false, false>(variant, G, g.grid, g.threads, g.lds, s)));
+    HIP_TRY(generic_launch_m<false>(g.mem, variant, G, g.grid, g.threads, g.lds, s));
     return QBP_OK;
 }
 
@@ -1412,6 +1432,8 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
             return QBP_OK;
         case QBP_OPT_GENERAL_NO_LDS_TABLES:
             h->opt_no_lds_tables = value != 0; return QBP_OK;
+        case QBP_OPT_GENERAL_NO_R_SPLIT:
+            h->opt_no_r_split = value != 0; return QBP_OK;
         case QBP_OPT_GENERAL_THREADS:
             if (value < 0 || value > 1024) return fail(QBP_E_INVALID, "threads per workgroup out of range");
             h->opt_threads = (int)value; return QBP_OK;

@@ -76,6 +76,7 @@ struct GenericParams {
     const double* prior_sorted; // [n] prior of the sorted variable x (permuted once per call)
     int lds_tables;             // 1: every workgroup keeps its own copy of vpos and prior_sorted in LDS
                                 // (read once per kernel instead of once per iteration from L2)
+    int r_split;                // GENERIC_MEM_SPLIT: doubles of R held in LDS (positions below it)
     // ---- the call ---------------------------------------------------------------------------------
     const uint8_t* syndromes;
     long long B;
@@ -122,9 +123,10 @@ __host__ __device__ inline size_t generic_lds_words(int m)
     const size_t mw = ((size_t)m + 31) >> 5;
     return (((3 * mw + 2 + 1) & ~(size_t)1) + 4 + NUM_COUNTERS + 1) & ~(size_t)1;
 }
-__host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool lds_msgs, bool lds_tables)
+__host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool lds_msgs, bool lds_tables,
+                                                    int r_split = 0)
 {
-    return (lds_msgs ? (size_t)16 * (size_t)E : 0) + generic_lds_words(m) * 4 +
+    return (lds_msgs ? (size_t)16 * (size_t)E : (size_t)8 * (size_t)r_split) + generic_lds_words(m) * 4 +
            (lds_tables ? (size_t)8 * (size_t)n + (size_t)4 * (size_t)E : 0);
 }
 
@@ -183,31 +185,31 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
 // np.sum over the gathered column R[pos[0 .. n)] in numpy's pairwise order (the loop form of the
 // reference, decoding/beliefPropagation.py:68; oracle/bp_oracle.c:np_pairwise_sum states the
 // algorithm).  The recursion above 128 terms is unrolled LEVEL times (n <= 128 << LEVEL).
-template <int LEVEL>
-__device__ __forceinline__ double np_pairwise_gather(const double* R, const int32_t* pos, int n)
+template <int LEVEL, typename RAcc>
+__device__ __forceinline__ double np_pairwise_gather(const RAcc& R, const int32_t* pos, int n)
 {
     if (n < 8) {
         double res = 0.0;
-        for (int i = 0; i < n; ++i) res = (i == 0) ? R[pos[0]] : res + R[pos[i]];
+        for (int i = 0; i < n; ++i) res = (i == 0) ? R(pos[0]) : res + R(pos[i]);
         return res;
     }
     if (LEVEL == 0 || n <= 128) {
         double r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = R[pos[j]];
+        for (int j = 0; j < 8; ++j) r[j] = R(pos[j]);
         int i = 8;
         for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] += R[pos[i + j]];
+            for (int j = 0; j < 8; ++j) r[j] += R(pos[i + j]);
         }
         double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += R[pos[i]];
+        for (; i < n; ++i) res += R(pos[i]);
         return res;
     }
     if constexpr (LEVEL > 0) {
         int n2 = n / 2;
         n2 -= n2 % 8;
-        return np_pairwise_gather<LEVEL - 1>(R, pos, n2) + np_pairwise_gather<LEVEL - 1>(R, pos + n2, n - n2);
+        return np_pairwise_gather<LEVEL - 1, RAcc>(R, pos, n2) + np_pairwise_gather<LEVEL - 1, RAcc>(R, pos + n2, n - n2);
     }
     return 0.0;
 }
@@ -232,9 +234,20 @@ __global__ void generic_permute_prior(const double* prior, const int32_t* svar, 
 
 // __launch_bounds__(1024) = at most 128 registers: also right for the smaller launches, which then
 // fit several workgroups per CU.
-template <int VARIANT, bool MC, bool LDSMSG>
+// MEM: where one syndrome's 2E messages live --
+//   GENERIC_MEM_GLOBAL  Q and R in the per-workgroup global workspace (L2 / Infinity Cache);
+//   GENERIC_MEM_LDS     both in LDS (16 E bytes fit);
+//   GENERIC_MEM_SPLIT   Q in the global workspace, the first r_split doubles of R in LDS and the rest in
+//                       the workspace: R is written once and read once per iteration, so this removes up
+//                       to half of the traffic of a kernel that is bound by it (2592 x 7776: E doubles
+//                       are 896 bytes more than the LDS holds).  R is then reached through flat
+//                       pointers picked per access.
+constexpr int GENERIC_MEM_GLOBAL = 0, GENERIC_MEM_LDS = 1, GENERIC_MEM_SPLIT = 2;
+
+template <int VARIANT, bool MC, int MEM>
 __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
+    constexpr bool LDSMSG = MEM == GENERIC_MEM_LDS;
     extern __shared__ double gsm[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63;
@@ -247,8 +260,26 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         Q = gsm; R = gsm + E; words = reinterpret_cast<unsigned*>(gsm + 2 * (size_t)E);
     } else {
         Q = P.wsQ + (size_t)blockIdx.x * E; R = P.wsR + (size_t)blockIdx.x * E;
-        words = reinterpret_cast<unsigned*>(gsm);
+        words = reinterpret_cast<unsigned*>(gsm + (MEM == GENERIC_MEM_SPLIT ? P.r_split : 0));
     }
+    // check->variable message at layout position `pos` (split mode: an LDS access or a global one,
+    // under the lanes' own masks -- whole wavefronts on one side skip the other)
+    auto Rload = [&](int pos) -> double {
+        if constexpr (MEM == GENERIC_MEM_SPLIT) {
+            double v;
+            if (pos < P.r_split) v = gsm[pos]; else v = R[pos];
+            return v;
+        } else {
+            return R[pos];
+        }
+    };
+    auto Rstore = [&](int pos, double v) {
+        if constexpr (MEM == GENERIC_MEM_SPLIT) {
+            if (pos < P.r_split) gsm[pos] = v; else R[pos] = v;
+        } else {
+            R[pos] = v;
+        }
+    };
     const int mw = (m + 31) >> 5;
     unsigned* const synw = words;                   // [mw] syndrome bits, sorted check order
     unsigned* const par = words + mw;               // [2][mw] parity of H hard ^ s, by iteration parity
@@ -355,10 +386,10 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             pos = vpos_t + k0;
             double s = 0.0;
             if (pairwise && deg >= 8) {
-                s = np_pairwise_gather<GENERIC_PAIRWISE_LEVELS>(R, pos, deg);
+                s = np_pairwise_gather<GENERIC_PAIRWISE_LEVELS>(Rload, pos, deg);
             } else {
                 for (int j = 0; j < deg; ++j) {
-                    const double r = R[pos[j]];
+                    const double r = Rload(pos[j]);
                     s = (j == 0) ? r : s + r;                     // ascending check order
                 }
             }
@@ -382,7 +413,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                     const int32_t* const pos = vpos_t + o;
                     double s = 0.0;
                     for (int j = 0; j < D; ++j) {
-                        const double r = R[pos[(size_t)j * cnt]];
+                        const double r = Rload(pos[(size_t)j * cnt]);
                         s = (j == 0) ? r : s + r;
                     }
                     val = s + prior_t[x];
@@ -459,7 +490,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         double q[DD], r[DD];                                                       \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = Q[base + j * cnt];   \
                         generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale);               \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) R[base + j * cnt] = r[j];   \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) Rstore(base + j * cnt, r[j]);   \
                     }                                                                              \
                 } break;
                 switch (D) {
@@ -476,7 +507,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             if (n_long > 0) {                                           // uniform
                 double* const L = P.wsL + (size_t)blockIdx.x * 3 * n_long;
                 if constexpr (VARIANT != 2) {
-                    for (int k = tid; k < n_ledges; k += nt) R[lbase + k] = tanh_half_msg<VARIANT>(Q[lbase + k]);
+                    for (int k = tid; k < n_ledges; k += nt) Rstore(lbase + k, tanh_half_msg<VARIANT>(Q[lbase + k]));
                     __syncthreads();
                 }
                 for (int i = tid; i < n_long; i += nt) {
@@ -506,11 +537,11 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         for (; j + 8 <= deg; j += 8) {
                             double a[8];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) a[u] = R[p0 + j + u];
+                            for (int u = 0; u < 8; ++u) a[u] = Rload(p0 + j + u);
 #pragma unroll
                             for (int u = 0; u < 8; ++u) prod = (j + u == 0) ? a[0] : prod * a[u];
                         }
-                        for (; j < deg; ++j) prod = (j == 0) ? R[p0] : prod * R[p0 + j];
+                        for (; j < deg; ++j) prod = (j == 0) ? Rload(p0) : prod * Rload(p0 + j);
                         L[3 * i] = prod;
                     }
                 }
@@ -524,20 +555,20 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const double sg = x < 0.0 ? -1.0 : 1.0;
                         const double mag = (__builtin_fabs(x) == L[3 * i + 1]) ? L[3 * i + 2] : L[3 * i + 1];
                         const double as = sbit ? -P.alpha : P.alpha;
-                        R[lbase + k] = (as * (L[3 * i] * sg)) * mag;
+                        Rstore(lbase + k, (as * (L[3 * i] * sg)) * mag);
                     } else {
-                        const double t = R[lbase + k];
+                        const double t = Rload(lbase + k);
                         const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
                         double po = div_nr(L[3 * i], ts);
                         po = sbit ? -po : po;
                         const double x = atanh2(clip_unit<VARIANT>(po));
-                        R[lbase + k] = (VARIANT == 1 && scale) ? x * P.alpha : x;
+                        Rstore(lbase + k, (VARIANT == 1 && scale) ? x * P.alpha : x);
                     }
                 }
             }
             __syncthreads();                                          // ---- barrier A
             if (!scale) {
-                for (int e = tid; e < E; e += nt) P.dump_R[b * E + e] = R[P.epos[e]] / P.dump_div;
+                for (int e = tid; e < E; e += nt) P.dump_R[b * E + e] = Rload(P.epos[e]) / P.dump_div;
                 frozen = true;           // nothing else is reported for this syndrome
                 break;
             }
@@ -572,7 +603,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         int o[DD];                                                                 \
                         double r[DD];                                                              \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = vpos_t[base + j * cnt]; \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = R[o[j]];             \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = Rload(o[j]);             \
                         double s = r[0];                                                           \
                         _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];               \
                         const double val = s + prior_t[P.col_off[DD] + i];                  \
@@ -596,7 +627,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                     const int32_t* const row = P.vrow + (pos - vpos_t);
                     for (int j = 0; j < deg; ++j) flip(row[j]);
                 }
-                for (int j = 0; j < deg; ++j) q_update(pos[j], val, R[pos[j]]);
+                for (int j = 0; j < deg; ++j) q_update(pos[j], val, Rload(pos[j]));
             }
             if (delta) atomicAdd(&unsat[p], delta);
             __syncthreads();                                          // ---- barrier B

@@ -15,6 +15,8 @@ from qldpc_amd import _lib, bp, codes  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default=None)
 ap.add_argument("--quick", action="store_true", help="default geometry only (A/B of library variants)")
+ap.add_argument("--no-r-split", action="store_true")
+ap.add_argument("--no-lds-tables", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 
@@ -42,6 +44,8 @@ for name, H, B in (("288", H288, 65536), ("st864", space_time(H144, 12), 32768),
     from scipy.sparse import csr_matrix
     dec = bp.decoder_for(csr_matrix(H))
     dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_GENERAL)
+    dec.set_option(_lib.OPT_GENERAL_NO_R_SPLIT, int(args.no_r_split))
+    dec.set_option(_lib.OPT_GENERAL_NO_LDS_TABLES, int(args.no_lds_tables))
     st = torch.cuda.current_stream(dev)
 
     def run():
