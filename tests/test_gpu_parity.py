@@ -46,11 +46,12 @@ def test_hip_vs_oracle_fresh(name, p, B):
     assert np.array_equal(hard, o_hard)
     rel = np.abs(llr - o_llr) / np.maximum(np.abs(o_llr), 1e-300)
     relrow = rel.max(1)
-    # BASELINE.json: posterior LLRs within 1e-5 relative.  Holds element-wise for every syndrome
-    # that converges within 20 iterations (measured worst 4.3e-6 over 20 000 syndromes).  The few
-    # that wander for 21-49 chaotic iterations before converging amplify the last-ulp differences between ANY two
-    # tanh/atanh implementations (oracle: glibc; device: qbp_math.hpp; the reference: numpy SIMD)
-    # exactly like the non-converged ones do (hard part 1): bounded, and reported.
+    # BASELINE.json: posterior LLRs within 1e-5 relative.  Here (device against the CPU oracle, two
+    # independent implementations of tanh/atanh, fresh syndromes the reference never saw): 1e-5
+    # element-wise on every syndrome that converges within 20 iterations.  What happens later, where
+    # last-ulp differences are amplified by every further iteration, is pinned against the REAL
+    # reference and its own self-spread in tests/test_late_golden.py (per convergence-iteration
+    # bucket); here those syndromes only get the absolute drift bound and are reported.
     early = conv & (iters <= 20)
     late = conv & (iters > 20)
     assert relrow[early].max() <= 1e-5

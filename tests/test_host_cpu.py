@@ -223,18 +223,30 @@ def test_bench_accounting_and_committed_line():
     # [[288,12,18]]: E = 864, m = 144, n = 288 -> 27 648 B per iteration, 2 741 B of I/O per syndrome
     assert bench.algorithmic_bytes(864, 144, 288, 1, 0) == 27648
     assert bench.algorithmic_bytes(864, 144, 288, 50, 1) == 1382400 + 2741
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_1gpu.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_1gpu.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline",
+                "hbm_effective", "early_exit", "stress_p010", "sustained", "dropin_api"):
         assert key in line, key
     assert line["scaling"] == "weak" and line["dtype"] == "f64" and line["vs_baseline"] is None
     assert "workload" in line["config"] and "model" not in line["config"]
     r = line["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["unit"] == "GB/s" and r["traffic"] is not None
+    # the binding resource of the on-chip kernel, measured by the run: a fraction of a real ceiling
+    assert r["bound"] == "fp64_valu" and 0.0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    needed = r["issue_cycles_per_wave_iteration"] * r["wave_iterations_per_launch"]
+    available = r["simds"] * r["kernel_ms"] * 1e-3 * r["max_clock_GHz"] * 1e9
+    assert abs(r["frac"] - needed / available) < 1e-9
+    assert sum(r["valu_by_class"].values()) == r["valu_insts_per_wave_iteration"]
+    assert line["hbm_effective"]["unit"] == "GB/s"       # the north star's yardstick, kept beside it
+    assert line["sustained"]["seconds"] >= 9.5 and 0.9 < line["sustained"]["ratio_to_headline"] < 1.1
+    assert 0.95 < line["stress_p010"]["ratio_to_headline_kernel_ms"] < 1.05
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c
+    assert c["reference_python"]["measured_by_this_run"] is False
     assert line["value"] > 1e6            # the north star's floor
+    two = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_2rank_gloo_rehearsal.json")))
+    assert two["n_gpus"] == 2 and two["multi_gpu"]["n_ranks_seen"] == 2
 
 
 def test_self_launch_command_and_supervisor(tmp_path):
