@@ -198,6 +198,8 @@ enum {
     QBP_OPT_KERNEL = 5,          /* 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome),
                                     3 streaming (lane per syndrome, messages in HBM)          */
     QBP_OPT_GENERAL_THREADS = 6, /* general-H kernel: threads per workgroup (0 = auto)        */
+    QBP_OPT_GENERAL_MEM = 10,          /* general-H kernel, where the messages live: 0 auto (LDS when they fit),
+                                          1 global workspace, 2 Q global + half of R in LDS (tests) */
     QBP_OPT_GENERAL_NO_R_SPLIT = 9,    /* 1 = general-H kernel keeps all of R in its global workspace (A/B) */
     QBP_OPT_GENERAL_NO_LDS_TABLES = 8, /* 1 = general-H kernel reads its variable-step tables from L2 (A/B) */
     QBP_OPT_OSD_BIG = 7,         /* 1 = OSD-0 through the workgroup-per-syndrome kernel (matrix in

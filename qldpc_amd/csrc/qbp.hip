@@ -135,6 +135,7 @@ struct qbp_handle {
     int opt_threads = 0;            // general-H kernel: threads per workgroup (0 = auto)
     int opt_no_lds_tables = 0;      // general-H kernel: keep the variable step's tables in L2 (A/B)
     int opt_no_r_split = 0;         // general-H kernel: no part of R in LDS when the messages do not fit (A/B)
+    int opt_mem = 0;                // general-H kernel: 0 auto, 1 messages in global memory, 2 half of R in LDS (tests)
     int row_base[qbp::GENERIC_MAX_ROW_CLASS + 2] = {0};
     int row_off[qbp::STREAM_MAX_ROW_CLASS + 3] = {0};
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
@@ -496,7 +497,7 @@ static GenericGeom generic_geometry(const qbp_handle* h, long long B)
     GenericGeom g{};
     const int E1 = std::max(h->E, 1);
     constexpr size_t LDS_MAX = (size_t)160 * 1024;
-    g.lds_msgs = qbp::generic_lds_bytes(h->m, E1, h->n, true, false) <= LDS_MAX;
+    g.lds_msgs = qbp::generic_lds_bytes(h->m, E1, h->n, true, false) <= LDS_MAX && h->opt_mem == 0;
     // the variable step's tables (prior, message positions) in LDS too when one workgroup per CU is
     // the geometry anyway and they fit beside (or instead of) the messages
     g.lds_tables = false;
@@ -522,10 +523,12 @@ static GenericGeom generic_geometry(const qbp_handle* h, long long B)
     if (h->opt_blocks_per_cu > 0) per_cu = h->opt_blocks_per_cu;
     g.mem = g.lds_msgs ? qbp::GENERIC_MEM_LDS : qbp::GENERIC_MEM_GLOBAL;
     g.r_split = 0;
-    if (!g.lds_msgs && per_cu == 1 && !h->opt_no_r_split) {
+    if (h->opt_mem == 2) per_cu = 1;
+    if (!g.lds_msgs && per_cu == 1 && !h->opt_no_r_split && h->opt_mem != 1) {
         // the messages do not fit: as much of R as the LDS holds (the rest, and Q, in the workspace)
         const size_t room = LDS_MAX - qbp::generic_lds_bytes(h->m, E1, h->n, false, false);
-        const int K = (int)std::min<size_t>((size_t)E1, room / 8);
+        int K = (int)std::min<size_t>((size_t)E1, room / 8);
+        if (h->opt_mem == 2) K = std::min(K, std::max(1, E1 / 2));     // (tests: both sides of the split in use)
         if (K >= E1 / 4) { g.mem = qbp::GENERIC_MEM_SPLIT; g.r_split = K; }
         g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, false, false, g.r_split);
     }
@@ -1434,6 +1437,9 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
             h->opt_no_lds_tables = value != 0; return QBP_OK;
         case QBP_OPT_GENERAL_NO_R_SPLIT:
             h->opt_no_r_split = value != 0; return QBP_OK;
+        case QBP_OPT_GENERAL_MEM:
+            if (value < 0 || value > 2) return fail(QBP_E_INVALID, "memory mode out of range");
+            h->opt_mem = (int)value; return QBP_OK;
         case QBP_OPT_GENERAL_THREADS:
             if (value < 0 || value > 1024) return fail(QBP_E_INVALID, "threads per workgroup out of range");
             h->opt_threads = (int)value; return QBP_OK;

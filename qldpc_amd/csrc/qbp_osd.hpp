@@ -220,7 +220,7 @@ struct OsdBigWorkspace {
 __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const OsdBigWorkspace Wk)
 {
     extern __shared__ double osd_smem[];
-    __shared__ int s_piv;
+    __shared__ int s_piv[2];        // (two slots, by column parity: see the pivot search)
     __shared__ unsigned long long s_lm;
     __shared__ int s_ew, s_df, s_bad;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -281,14 +281,17 @@ __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const 
             const int c = idx[k];
             const uint32_t* const colw = At + (size_t)(c >> 5) * m;
             const uint32_t bit = 1u << (c & 31);
-            if (tid == 0) s_piv = 0x7fffffff;
+            // (slot k & 1: a column without pivot leaves this iteration without a trailing barrier, so the
+            // next column's reset must not touch the word the slower threads are still reading)
+            int* const piv = &s_piv[k & 1];
+            if (tid == 0) *piv = 0x7fffffff;
             __syncthreads();
             int mine = 0x7fffffff;
             for (int r = tid; r < m; r += nt)
                 if ((colw[r] & bit) && pivcol[r] < 0) { mine = r; break; }     // this thread's first
-            if (mine != 0x7fffffff) atomicMin(&s_piv, mine);
+            if (mine != 0x7fffffff) atomicMin(piv, mine);
             __syncthreads();
-            const int p = s_piv;                      // the first unused row with a 1 (:46-50)
+            const int p = *piv;                       // the first unused row with a 1 (:46-50)
             if (p == 0x7fffffff) continue;            // column depends on earlier ones (:52-53)
             ++rank;
             for (int r = tid; r < m; r += nt) {

@@ -151,6 +151,19 @@ def test_fuzz_decode_kernels_vs_oracle():
         for k in (_lib.KERNEL_GENERAL, _lib.KERNEL_STREAM):
             for x, y in zip(a, outs[k]):
                 assert np.array_equal(x, y, equal_nan=True), f"kernel {k} differs from the default: {tag}"
+        # the general-H kernel's other memory modes (messages in its global workspace; Q there and
+        # half of R in LDS), which large matrices select by themselves
+        if case % 3 == 0:
+            for mem in (1, 2):
+                dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_GENERAL)
+                dec.set_option(_lib.OPT_GENERAL_MEM, mem)
+                try:
+                    alt = dec.decode(syn, prior, max_iter, variant, flags=flags, **kw)
+                finally:
+                    dec.set_option(_lib.OPT_GENERAL_MEM, 0)
+                    dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
+                for x, y in zip(a, alt):
+                    assert np.array_equal(x, y, equal_nan=True), f"general-H memory mode {mem} differs: {tag}"
 
         o = oracle.decode_batch(H, syn, prior, max_iter, variant, threads=8, **kw)
         same = (a[0] == o[0]).all(axis=1) & (a[1] == o[1]) & (a[2] == o[2])

@@ -214,3 +214,29 @@ def test_mc_osd_general_kernel_equals_on_chip_kernel():
     g.set_option(_lib.OPT_OSD_BIG, 1)
     c = g.mc_run(code.Lx, code.distance, p, prior, 3, 20003, seed=1, flags=_lib.FLAG_OSD0)
     assert np.array_equal(a, c), (a, c)
+
+
+@pytest.mark.parametrize("name,p,T", [("[[72, 12, 6]]", 0.06, 20000), ("[[288, 12, 18]]", 0.06, 6000)])
+def test_mc_osd_counters_trial_for_trial(name, p, T):
+    """The BP+OSD Monte-Carlo counters, EXACTLY, on the OSD branch too.  Against the oracle pipeline a
+    few trials per 1e5 may end in another member of the same coset, because the oracle's and the
+    device's LLRs of non-converged trials differ in the last digits and OSD-0 orders columns by them
+    (test_mc_bp_osd_counters_match_oracle allows for that).  Here the pipeline is replayed on the
+    device's OWN BP outputs: same Philox errors (bit-identical to the oracle's sampler), decode through
+    qbp_decode_batch (the Monte-Carlo build computes the same bits), the ORACLE's OSD-0 on those LLRs,
+    the oracle's classification -- all 12 counters of qbp_mc_run(QBP_FLAG_OSD0) must then be equal."""
+    code = codes.load_code(name)
+    dec = bp.decoder_for(code.Hx)
+    prior = mc.prior_of(p, code.n)
+    errors = oracle.mc_errors(code.n, p, 1, 11, 100, T)
+    assert np.array_equal(errors, dec.mc_sample_errors(p, 100, T, seed=11))
+    syn = (errors.astype(np.int64) @ code.Hx.T % 2).astype(np.uint8)
+    hard, conv, iters, llr = dec.decode(syn, prior, 50)
+    det = hard.copy()
+    for i in np.flatnonzero(~conv):
+        det[i] = oracle.osd0(code.Hx, syn[i], llr[i], hard[i])
+    want = oracle.classify_trials(code.Hx, code.Lx, code.distance, errors, syn, det, conv, iters)
+    got = dec.mc_run(code.Lx, code.distance, p, prior, 100, 100 + T, seed=11, max_iter=50, flags=_lib.FLAG_OSD0)
+    print(dict(zip(_lib.COUNTER_NAMES, got.tolist())), "BP failures:", int((~conv).sum()))
+    assert (~conv).sum() > 100
+    assert np.array_equal(got, want), (got, want)
