@@ -17,6 +17,7 @@
 #include "qbp_generic.hpp"
 #include "qbp_stream.hpp"
 #include "qbp_hist.hpp"
+#include "qbp_launch.hpp"
 
 static_assert(QBP_NUM_COUNTERS == qbp::NUM_COUNTERS, "counter layout");
 
@@ -48,11 +49,7 @@ int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
-// (row weight, column weight) shapes the on-chip kernel is instantiated for: every code of the
-// reference's codes/ is (6, 3); (8, 4) covers their space-time matrices (spaceTime.py: row weight
-// 6 + 2, column weight 3).  Anything wider, or with m > 1024, goes to the general-H kernel.
-constexpr int DC_SMALL = 6, DV_SMALL = 3;
-constexpr int DC_WIDE = 8, DV_WIDE = 4;
+using qbp::DC_SMALL; using qbp::DV_SMALL; using qbp::DC_WIDE; using qbp::DV_WIDE;
 
 // Makes `device` current for the lifetime of the object and restores the caller's device
 // afterwards (entry points must not leave a host thread on another GPU than they found it on).
@@ -170,51 +167,7 @@ namespace {
 
 using qbp::FusedParams;
 
-struct LaunchCfg {
-    int S, threads, lds_bytes, grid, slot_stride, dc;
-};
-
-template <int DC, int DV, int VARIANT, bool MC, bool FORCE, int MAXT, int MINW>
-hipError_t launch_k(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
-{
-    auto kern = qbp::bp_fused_kernel<DC, DV, VARIANT, MC, FORCE, MAXT, MINW>;
-    // the dynamic-LDS limit of an instantiation is raised once per device and size (the attribute
-    // call costs a few microseconds, which matters for one-syndrome-per-call users)
-    static thread_local int lds_set[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || lds_set[dev] < cfg.lds_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) lds_set[dev] = cfg.lds_bytes;
-    }
-    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(cfg.threads), cfg.lds_bytes, stream, P);
-    return hipGetLastError();
-}
-
-template <int VARIANT, bool MC, int MAXT, int MINW = 1>
-hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
-{
-    const bool force = (P.flags & QBP_FLAG_FORCE_FULL) != 0;
-    if (cfg.dc == DC_SMALL)
-        return force ? launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
-                     : launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
-    return force ? launch_k<DC_WIDE, DV_WIDE, VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
-                 : launch_k<DC_WIDE, DV_WIDE, VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
-}
-
-template <bool MC>
-hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s)
-{
-    // __launch_bounds__(1024): 128-VGPR budget = 4 wavefronts per SIMD, the fastest geometry
-    // measured (profiles/r01_tune.txt; builds with 3 or 5 waves per SIMD were slower).
-    switch (variant) {
-        case QBP_SUM_PRODUCT: return launch_one<0, MC, 1024>(P, cfg, s);
-        case QBP_DAMPED_SP:   return launch_one<1, MC, 1024>(P, cfg, s);
-        default:              return launch_one<2, MC, 1024>(P, cfg, s);
-    }
-}
+using qbp::LaunchCfg;
 
 // Dynamic LDS of one workgroup of the fused kernel (the carve is documented in qbp_kernels.hpp)
 size_t fused_lds_bytes(int dc, int m, int n, int S)
@@ -446,45 +399,6 @@ void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg)
 
 }  // namespace
 
-template <int VARIANT, bool MC, int MEM>
-static hipError_t generic_launch_k(const qbp::GenericParams& G, int grid, int threads, size_t lds, hipStream_t s)
-{
-    auto kern = qbp::bp_generic_kernel<VARIANT, MC, MEM>;
-    static thread_local size_t lds_set[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || lds_set[dev] < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) lds_set[dev] = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, G);
-    return hipGetLastError();
-}
-
-template <bool MC, int MEM>
-static hipError_t generic_launch_v(int variant, const qbp::GenericParams& G, int grid, int threads, size_t lds,
-                                   hipStream_t s)
-{
-    switch (variant) {
-        case QBP_SUM_PRODUCT: return generic_launch_k<0, MC, MEM>(G, grid, threads, lds, s);
-        case QBP_DAMPED_SP:   return generic_launch_k<1, MC, MEM>(G, grid, threads, lds, s);
-        default:              return generic_launch_k<2, MC, MEM>(G, grid, threads, lds, s);
-    }
-}
-
-template <bool MC>
-static hipError_t generic_launch_m(int mem, int variant, const qbp::GenericParams& G, int grid, int threads,
-                                   size_t lds, hipStream_t s)
-{
-    switch (mem) {
-        case qbp::GENERIC_MEM_LDS:   return generic_launch_v<MC, qbp::GENERIC_MEM_LDS>(variant, G, grid, threads, lds, s);
-        case qbp::GENERIC_MEM_SPLIT: return generic_launch_v<MC, qbp::GENERIC_MEM_SPLIT>(variant, G, grid, threads, lds, s);
-        default:                     return generic_launch_v<MC, qbp::GENERIC_MEM_GLOBAL>(variant, G, grid, threads, lds, s);
-    }
-}
-
 // Launch geometry of the general-H kernel (one workgroup per syndrome at a time):
 //   messages in LDS when they fit (16 E bytes + bookkeeping <= 160 KiB), else in a global workspace;
 //   threads per workgroup: the checks of weight <= 8 in as few, as full passes as possible
@@ -561,9 +475,7 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
         HIP_TRY(h->d_wsR.reserve((size_t)g.grid * E));
     }
     HIP_TRY(h->d_prior_sorted.reserve(n));
-    hipLaunchKernelGGL(qbp::generic_permute_prior, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_prior,
-                       h->d_svar.p, h->d_prior_sorted.p, (int)n);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(qbp::launch_permute_prior(d_prior, h->d_svar.p, h->d_prior_sorted.p, (int)n, s));
     qbp::GenericParams G{};
     G.m = h->m; G.n = h->n; G.E = h->E;
     G.srow = h->d_srow.p; G.srow_e0 = h->d_srow_e0.p; G.srow_deg = h->d_srow_deg.p;
@@ -598,10 +510,10 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
         G.counters = mc->counters; G.wsE = h->d_wsE.p;
         G.fail_list = mc->fail_list; G.fail_count = mc->fail_count; G.fail_syn = mc->fail_syn;
         G.fail_llr = mc->fail_llr; G.fail_hard = mc->fail_hard; G.fail_err = mc->fail_err;
-        HIP_TRY(generic_launch_m<true>(g.mem, variant, G, g.grid, g.threads, g.lds, s));
+        HIP_TRY(qbp::launch_generic(true, g.mem, variant, G, g.grid, g.threads, g.lds, s));
         return QBP_OK;
     }
-    HIP_TRY(generic_launch_m<false>(g.mem, variant, G, g.grid, g.threads, g.lds, s));
+    HIP_TRY(qbp::launch_generic(false, g.mem, variant, G, g.grid, g.threads, g.lds, s));
     return QBP_OK;
 }
 
@@ -813,16 +725,8 @@ static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double
         const long long lanes = std::min<long long>(Bc, B - b0);
         const unsigned grid = (unsigned)((lanes + 255) / 256);
         h->last_threads = 256; h->last_lds = 0; h->last_grid = (int)grid;
-#define QBP_STREAM_LAUNCH(V) hipLaunchKernelGGL((qbp::bp_stream_kernel<V>), dim3(grid), dim3(256), 0, s, P, \
-        h->d_col_idx.p, h->d_col_ptr.p, h->d_col_edge.p, d_prior, h->d_srow.p, h->d_srow_e0.p,             \
-        h->d_srow_deg.p, h->d_svar.p, h->d_sedge.p)
-        switch (variant) {
-            case QBP_SUM_PRODUCT: QBP_STREAM_LAUNCH(0); break;
-            case QBP_DAMPED_SP:   QBP_STREAM_LAUNCH(1); break;
-            default:              QBP_STREAM_LAUNCH(2); break;
-        }
-#undef QBP_STREAM_LAUNCH
-        HIP_TRY(hipGetLastError());
+HIP_TRY(qbp::launch_stream(variant, grid, P, h->d_col_idx.p, h->d_col_ptr.p, h->d_col_edge.p, d_prior,
+                                   h->d_srow.p, h->d_srow_e0.p, h->d_srow_deg.p, h->d_svar.p, h->d_sedge.p, s));
     }
     return QBP_OK;
 }
@@ -873,7 +777,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     // >= B -- and the memset node is skipped (3 us of a 30 us single-syndrome call).
     if (B > (long long)cfg.grid * cfg.S)
         HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<false>(variant, P, cfg, s));
+    HIP_TRY(qbp::launch_fused(false, variant, P, cfg, s));
     return QBP_OK;
 }
 
@@ -1071,8 +975,7 @@ try {
     // range of all messages (rework/Alvarado.py:41-44: the two classes share one range)
     const int grid = (int)std::min<size_t>(1024, (b * E + 255) / 256);
     HIP_TRY(h->d_part.reserve((size_t)2 * grid));
-    hipLaunchKernelGGL(qbp::hist_minmax_kernel, dim3(grid), dim3(256), 0, s, h->d_llr.p, (long long)(b * E), h->d_part.p);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(qbp::launch_hist_minmax(grid, h->d_llr.p, (long long)(b * E), h->d_part.p, s));
     std::vector<double> part((size_t)2 * grid);
     HIP_TRY(hipMemcpyAsync(part.data(), h->d_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1090,9 +993,8 @@ try {
     HIP_TRY(hipMemcpyAsync(h->d_edges.p, edges, ((size_t)bins + 1) * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(h->d_hist.p, 0, (size_t)2 * bins * sizeof(unsigned long long), s));
     const size_t lds = (((size_t)2 * bins + 1) & ~(size_t)1) * 4 + ((size_t)bins + 1) * 8;
-    hipLaunchKernelGGL(qbp::hist_bin_kernel, dim3(grid), dim3(256), lds, s, h->d_llr.p, h->d_hard.p, h->d_col_idx.p,
-                       (long long)B, (int)E, (int)n, h->d_edges.p, bins, h->d_hist.p);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(qbp::launch_hist_bin(grid, lds, h->d_llr.p, h->d_hard.p, h->d_col_idx.p, (long long)B, (int)E, (int)n,
+                                 h->d_edges.p, bins, h->d_hist.p, s));
     std::vector<unsigned long long> hist((size_t)2 * bins);
     HIP_TRY(hipMemcpyAsync(hist.data(), h->d_hist.p, hist.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1190,30 +1092,12 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
         Wk.At = h->d_osd_At.p; Wk.pivcol = h->d_osd_piv.p; Wk.sol = h->d_osd_sol.p;
         Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
         const size_t lds = Wk.keys_in_lds ? NP * 12 : 0;
-        static thread_local size_t lds_set[64] = {0};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (lds > 0 && (dev < 0 || dev >= 64 || lds_set[dev] < lds)) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qbp::osd0_big_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (dev >= 0 && dev < 64) lds_set[dev] = lds;
-        }
-        hipLaunchKernelGGL(qbp::osd0_big_kernel, dim3((unsigned)grid), dim3(256), lds, s, O, Wk);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(qbp::launch_osd_big((unsigned)grid, lds, O, Wk, s));
         return QBP_OK;
     }
     O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
     const long long grid = std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 32));
-    // row width (32-bit words incl. the syndrome word) as a template argument for the codes of the
-    // reference: n = 72 / 90 / 108 -> 4 or 5, 144 -> 6, 288 -> 10
-    switch (h->osd_W + 1) {
-#define QBP_OSD_CASE(WW) case WW: hipLaunchKernelGGL(qbp::osd0_kernel<WW>, dim3((unsigned)grid), dim3(64), h->osd_lds, s, O); break
-        QBP_OSD_CASE(2); QBP_OSD_CASE(3); QBP_OSD_CASE(4); QBP_OSD_CASE(5); QBP_OSD_CASE(6);
-        QBP_OSD_CASE(7); QBP_OSD_CASE(8); QBP_OSD_CASE(9); QBP_OSD_CASE(10); QBP_OSD_CASE(11);
-#undef QBP_OSD_CASE
-        default: hipLaunchKernelGGL(qbp::osd0_kernel<0>, dim3((unsigned)grid), dim3(64), h->osd_lds, s, O);
-    }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(qbp::launch_osd_small(h->osd_W + 1, (unsigned)grid, (size_t)h->osd_lds, O, s));
     return QBP_OK;
 }
 
@@ -1335,7 +1219,7 @@ try {
         P.fail_hard = h->d_fail_hard.p; P.fail_err = h->d_fail_err.p;
     }
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<true>(variant, P, cfg, s));
+    HIP_TRY(qbp::launch_fused(true, variant, P, cfg, s));
     h->last_kernel = 1;
     if (osd) {
         rc = osd_pass();
@@ -1403,7 +1287,7 @@ try {
     P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = 0;
     P.counters = h->d_counters.p; P.errors_out = h->d_hard.p;
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(launch_variant<true>(QBP_MIN_SUM, P, cfg, s));
+    HIP_TRY(qbp::launch_fused(true, QBP_MIN_SUM, P, cfg, s));
     HIP_TRY(hipMemcpyAsync(errors, h->d_hard.p, (size_t)T * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
@@ -1479,11 +1363,7 @@ int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int6
     HIP_TRY(h->d_mathy.reserve((size_t)count));
     hipStream_t s = h->stream;
     HIP_TRY(hipMemcpyAsync(h->d_mathx.p, x, (size_t)count * sizeof(double), hipMemcpyHostToDevice, s));
-    const int threads = 256;
-    const long long blocks = (count + threads - 1) / threads;
-    hipLaunchKernelGGL(qbp::debug_math_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, kind,
-                       h->d_mathx.p, h->d_mathy.p, (long long)count);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(qbp::launch_debug_math(kind, h->d_mathx.p, h->d_mathy.p, (long long)count, s));
     HIP_TRY(hipMemcpyAsync(y, h->d_mathy.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;

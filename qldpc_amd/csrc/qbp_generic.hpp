@@ -225,12 +225,15 @@ __device__ __forceinline__ void generic_col_class(const GenericParams& P, int x,
     else                       { D = 4; cnt = P.col_off[5] - P.col_off[4]; o = P.col_base[4] + (x - P.col_off[4]); }
 }
 
+#ifdef QBP_DEFINE_KERNELS   /* non-template kernels: defined in their translation unit only */
 // Once per decode call: prior of the sorted variable x.
 __global__ void generic_permute_prior(const double* prior, const int32_t* svar, double* out, int n)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x < n) out[x] = prior[svar[x]];
 }
+
+#endif  // QBP_DEFINE_KERNELS
 
 // __launch_bounds__(1024) = at most 128 registers: also right for the smaller launches, which then
 // fit several workgroups per CU.

@@ -15,6 +15,7 @@
 
 namespace qbp {
 
+#ifdef QBP_DEFINE_KERNELS   /* non-template kernels: defined in their translation unit only */
 // per-block minimum / maximum of x[0 .. count)
 __global__ __launch_bounds__(256) void hist_minmax_kernel(const double* x, long long count, double* part /*[2 * grid]*/)
 {
@@ -68,5 +69,7 @@ __global__ __launch_bounds__(256) void hist_bin_kernel(const double* msg, const 
     for (int i = threadIdx.x; i < 2 * bins; i += blockDim.x)
         if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
+
+#endif  // QBP_DEFINE_KERNELS
 
 }  // namespace qbp

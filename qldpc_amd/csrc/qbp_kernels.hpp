@@ -576,6 +576,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     }
 }
 
+#ifdef QBP_DEFINE_KERNELS   /* non-template kernels: defined in their translation unit only */
 // Device evaluation of the math functions (accuracy tests).
 __global__ void debug_math_kernel(int kind, const double* x, double* y, long long n)
 {
@@ -589,5 +590,7 @@ __global__ void debug_math_kernel(int kind, const double* x, double* y, long lon
         default: y[i] = div_nr(1.0, v); break;
     }
 }
+
+#endif  // QBP_DEFINE_KERNELS
 
 }  // namespace qbp

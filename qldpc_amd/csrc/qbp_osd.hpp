@@ -217,6 +217,7 @@ struct OsdBigWorkspace {
     int keys_in_lds;
 };
 
+#ifdef QBP_DEFINE_KERNELS   /* non-template kernel: defined in its translation unit only */
 __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const OsdBigWorkspace Wk)
 {
     extern __shared__ double osd_smem[];
@@ -353,5 +354,7 @@ __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const 
         __syncthreads();
     }
 }
+
+#endif  // QBP_DEFINE_KERNELS
 
 }  // namespace qbp

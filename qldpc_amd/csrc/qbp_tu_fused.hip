@@ -1,0 +1,69 @@
+// libqbp.so, translation unit of the on-chip kernel (qbp_kernels.hpp): its 24 instantiations.
+#define QBP_DEFINE_KERNELS 1
+#include <hip/hip_runtime.h>
+
+#include "../../include/qbp.h"
+#include "qbp_kernels.hpp"
+#include "qbp_launch.hpp"
+
+namespace qbp {
+namespace {
+
+template <int DC, int DV, int VARIANT, bool MC, bool FORCE, int MAXT, int MINW>
+hipError_t launch_k(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
+{
+    auto kern = bp_fused_kernel<DC, DV, VARIANT, MC, FORCE, MAXT, MINW>;
+    // the dynamic-LDS limit of an instantiation is raised once per device and size (the attribute
+    // call costs a few microseconds, which matters for one-syndrome-per-call users)
+    static thread_local int lds_set[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || lds_set[dev] < cfg.lds_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, cfg.lds_bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) lds_set[dev] = cfg.lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(cfg.threads), cfg.lds_bytes, stream, P);
+    return hipGetLastError();
+}
+
+template <int VARIANT, bool MC, int MAXT, int MINW = 1>
+hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
+{
+    const bool force = (P.flags & QBP_FLAG_FORCE_FULL) != 0;
+    if (cfg.dc == DC_SMALL)
+        return force ? launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
+                     : launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
+    return force ? launch_k<DC_WIDE, DV_WIDE, VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
+                 : launch_k<DC_WIDE, DV_WIDE, VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);
+}
+
+template <bool MC>
+hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s)
+{
+    // __launch_bounds__(1024): 128-VGPR budget = 4 wavefronts per SIMD, the fastest geometry
+    // measured (profiles/r01_tune.txt; builds with 3 or 5 waves per SIMD were slower).
+    switch (variant) {
+        case QBP_SUM_PRODUCT: return launch_one<0, MC, 1024>(P, cfg, s);
+        case QBP_DAMPED_SP:   return launch_one<1, MC, 1024>(P, cfg, s);
+        default:              return launch_one<2, MC, 1024>(P, cfg, s);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_fused(bool mc, int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s)
+{
+    return mc ? launch_variant<true>(variant, P, cfg, s) : launch_variant<false>(variant, P, cfg, s);
+}
+
+hipError_t launch_debug_math(int kind, const double* x, double* y, long long count, hipStream_t s)
+{
+    const int threads = 256;
+    const long long blocks = (count + threads - 1) / threads;
+    hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, kind, x, y, count);
+    return hipGetLastError();
+}
+
+}  // namespace qbp

@@ -8,8 +8,8 @@ many vector instructions of which kind one wave executes per BP iteration.  That
 property of the machine code, so it is read from the machine code of the very library the run
 loads, not from a committed profile:
 
-1. the gfx950 code object is cut out of the library's ``.hip_fatbin`` section (clang offload bundle)
-   and disassembled with ROCm's ``llvm-objdump``;
+1. the gfx950 code objects are cut out of the library's ``.hip_fatbin`` section (one clang offload
+   bundle per translation unit) and disassembled with ROCm's ``llvm-objdump``;
 2. the kernel's main loop is the backward branch with the largest span;
 3. inside the loop, forward conditional branches delimit if-regions; a region is COLD when its own
    instructions (not those of nested regions) touch global memory or the kernel-argument segment --
@@ -51,53 +51,60 @@ CLASSES = [
 COLD = re.compile(r"^(global_|flat_|buffer_|s_load_|s_buffer_load|s_atomic|s_store|s_scratch)")
 
 
-def extract_code_object(so_path):
+def extract_code_objects(so_path):
+    """All gfx950 code objects of the library (one clang offload bundle per translation unit)."""
     with tempfile.TemporaryDirectory() as td:
         fat = os.path.join(td, "fatbin")
         subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}",
                                so_path, os.path.join(td, "copy.so")])
         d = open(fat, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    if not d.startswith(magic):
+    out, at = [], d.find(magic)
+    if at < 0:
         raise RuntimeError("no uncompressed clang offload bundle in .hip_fatbin")
-    n = struct.unpack_from("<Q", d, 24)[0]
-    off = 32
-    for _ in range(n):
-        o, s, tl = struct.unpack_from("<QQQ", d, off)
-        off += 24
-        triple = d[off:off + tl].decode()
-        off += tl
-        if "gfx950" in triple:
-            return d[o:o + s]
-    raise RuntimeError("no gfx950 code object in the bundle")
+    while at >= 0:
+        n = struct.unpack_from("<Q", d, at + 24)[0]
+        off = at + 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", d, off)
+            off += 24
+            triple = d[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple and sz:
+                out.append(d[at + o:at + o + sz])
+        at = d.find(magic, at + len(magic))
+    if not out:
+        raise RuntimeError("no gfx950 code object in the bundles")
+    return out
 
 
 def disassemble(so_path):
     """{symbol: [(addr, mnemonic, operands, branch_target_or_None)]}"""
-    co = extract_code_object(so_path)
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(co)
-        f.flush()
-        txt = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", f.name], text=True)
-    funcs, cur, base = {}, None, 0
+    funcs = {}
     head = re.compile(r"^([0-9a-f]+) <(\S+)>:")
     line = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):\s*[0-9A-Fa-f ]+(?:<\S+?\+0x([0-9a-f]+)>)?\s*$")
-    for ln in txt.splitlines():
-        mh = head.match(ln)
-        if mh:
-            base, cur = int(mh.group(1), 16), mh.group(2)
-            funcs[cur] = []
-            continue
-        ml = line.match(ln)
-        if ml and cur is not None:
-            mnem, ops, addr, tgt = ml.group(1), ml.group(2), int(ml.group(3), 16), ml.group(4)
-            target = None
-            if mnem.startswith("s_cbranch") or mnem == "s_branch":
-                if tgt is not None:
-                    target = base + int(tgt, 16)
-                elif re.search(r"<\S+>", ln):            # branch to the symbol itself (+0x0)
-                    target = base
-            funcs[cur].append((addr, mnem, ops, target))
+    for co in extract_code_objects(so_path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            txt = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", f.name], text=True)
+        cur, base = None, 0
+        for ln in txt.splitlines():
+            mh = head.match(ln)
+            if mh:
+                base, cur = int(mh.group(1), 16), mh.group(2)
+                funcs[cur] = []
+                continue
+            ml = line.match(ln)
+            if ml and cur is not None:
+                mnem, ops, addr, tgt = ml.group(1), ml.group(2), int(ml.group(3), 16), ml.group(4)
+                target = None
+                if mnem.startswith("s_cbranch") or mnem == "s_branch":
+                    if tgt is not None:
+                        target = base + int(tgt, 16)
+                    elif re.search(r"<\S+>", ln):            # branch to the symbol itself (+0x0)
+                        target = base
+                funcs[cur].append((addr, mnem, ops, target))
     return funcs
 
 
