@@ -446,7 +446,7 @@ static GenericGeom generic_geometry(const qbp_handle* h, long long B)
         if (K >= E1 / 4) { g.mem = qbp::GENERIC_MEM_SPLIT; g.r_split = K; }
         g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, false, false, g.r_split);
     }
-    if (per_cu == 1 && !h->opt_no_lds_tables &&
+    if (per_cu == 1 && !h->opt_no_lds_tables && g.mem != qbp::GENERIC_MEM_SPLIT &&
         qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split) <= LDS_MAX) {
         g.lds_tables = true;
         g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split);

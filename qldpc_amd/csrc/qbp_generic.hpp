@@ -247,6 +247,12 @@ __global__ void generic_permute_prior(const double* prior, const int32_t* svar, 
 //                       pointers picked per access.
 constexpr int GENERIC_MEM_GLOBAL = 0, GENERIC_MEM_LDS = 1, GENERIC_MEM_SPLIT = 2;
 
+#ifdef QBP_GEN_FAKE_Q       /* timing-only build: the check step's Q loads come from LDS (wrong results) */
+#define QBP_GEN_QLOAD(pos) fake_q(pos)
+#else
+#define QBP_GEN_QLOAD(pos) Q[pos]
+#endif
+
 template <int VARIANT, bool MC, int MEM>
 __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
@@ -269,16 +275,25 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
     // under the lanes' own masks -- whole wavefronts on one side skip the other)
     auto Rload = [&](int pos) -> double {
         if constexpr (MEM == GENERIC_MEM_SPLIT) {
+            // (the empty asm keeps the two sides apart: merged, they become ONE flat load through a
+            // selected pointer -- slower, and this compiler's backend then fails on some variants of
+            // the kernel with "Illegal instruction detected" around src_shared_base)
             double v;
-            if (pos < P.r_split) v = gsm[pos]; else v = R[pos];
+            if (pos < P.r_split) { v = gsm[pos]; asm volatile(""); } else { v = R[pos]; asm volatile(""); }
             return v;
         } else {
             return R[pos];
         }
     };
+#ifdef QBP_GEN_FAKE_Q
+    auto fake_q = [&](int pos) -> double {
+        if constexpr (MEM == GENERIC_MEM_SPLIT) return gsm[pos < P.r_split ? pos : pos - P.r_split];   // (LDS only)
+        else return Q[pos];
+    };
+#endif
     auto Rstore = [&](int pos, double v) {
         if constexpr (MEM == GENERIC_MEM_SPLIT) {
-            if (pos < P.r_split) gsm[pos] = v; else R[pos] = v;
+            if (pos < P.r_split) { gsm[pos] = v; asm volatile(""); } else { R[pos] = v; asm volatile(""); }
         } else {
             R[pos] = v;
         }
@@ -295,7 +310,9 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
     // tables of the variable step: from LDS when the launch reserved room for them, else from L2
     const double* prior_t = P.prior_sorted;
     const int32_t* vpos_t = P.vpos;
-    if (P.lds_tables) {
+    // (never together with a split R -- the LDS is full then -- and kept out of that instantiation at
+    // compile time: it then has no pointer that may or may not be an LDS address)
+    if (MEM != GENERIC_MEM_SPLIT && P.lds_tables) {
         double* const pt = reinterpret_cast<double*>(words + generic_lds_words(m));
         int32_t* const vt = reinterpret_cast<int32_t*>(pt + n);
         for (int i = tid; i < n; i += nt) pt[i] = P.prior_sorted[i];
@@ -491,7 +508,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const unsigned sbit = (synw[w >> 5] >> (w & 31)) & 1u;                     \
                         const int base = P.row_base[DD] + i;                                       \
                         double q[DD], r[DD];                                                       \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = Q[base + j * cnt];   \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = QBP_GEN_QLOAD(base + j * cnt);   \
                         generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale);               \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) Rstore(base + j * cnt, r[j]);   \
                     }                                                                              \
@@ -590,6 +607,10 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 delta += (old & bit) ? -1 : 1;
             };
 #ifndef QBP_GEN_SKIP_VAR
+            // (Measured and dropped: a software-pipelined form that requests the next pass's positions
+            // and prior before working on the current pass -- no gain on any matrix.  Where the messages
+            // live in L2 the step is bound by the rate of its scattered 8-byte stores of Q, one cache
+            // line per cycle and CU: 20 592 of them are the 8 us the step takes on 2592 x 7776.)
             for (int xp0 = tid - lane; xp0 < P.cpad_off[CC + 1]; xp0 += nt) {
                 const int xpu = __builtin_amdgcn_readfirstlane(xp0);
                 int D = 1;
@@ -606,10 +627,10 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         int o[DD];                                                                 \
                         double r[DD];                                                              \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = vpos_t[base + j * cnt]; \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = Rload(o[j]);             \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = Rload(o[j]);         \
                         double s = r[0];                                                           \
                         _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];               \
-                        const double val = s + prior_t[P.col_off[DD] + i];                  \
+                        const double val = s + prior_t[P.col_off[DD] + i];                         \
                         if (!frozen && val < 0.0) {                                                \
                             _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(P.vrow[base + j * cnt]); \
                         }                                                                          \
