@@ -63,21 +63,46 @@ def csr_from_H(H):
     return row_ptr, np.ascontiguousarray(cols, np.int32), int(A.shape[0]), int(A.shape[1])
 
 
+# Dense matrices above this size (the reference's space-time matrices: 2592 x 7776 float64 = 161 MB,
+# passed again on every one-syndrome call of studies/studyTT.py) are recognised by identity plus a
+# sampled checksum instead of a hash of all their bytes (30 ms per call for that matrix, against a
+# 0.1 - 0.9 ms decode).  QBP_STRICT_HASH=1 restores the full hash for every call.
+_FULL_HASH_LIMIT = 1 << 20
+_STRICT = os.environ.get("QBP_STRICT_HASH", "0") not in ("0", "")
+
+
 def _fingerprint(H, sparse):
-    """Cheap identity check of an array we have hashed before: same object, same buffer, same
-    shape / dtype / strides, and not writeable (a writeable array may have changed in place -- it is
-    re-hashed every time, as before)."""
-    if sparse:
+    """(buffer address, shape, dtype, strides) of an ndarray, else None."""
+    if sparse or not isinstance(H, np.ndarray):
         return None
-    a = H if isinstance(H, np.ndarray) else None
-    if a is None or a.flags.writeable:
-        return None
-    return (a.__array_interface__["data"][0], a.shape, a.dtype.str, a.strides)
+    return (H.__array_interface__["data"][0], H.shape, H.dtype.str, H.strides)
+
+
+def _sample_digest(A):
+    """Checksum of ~64k evenly spaced elements (large arrays only)."""
+    flat = A.reshape(-1) if A.flags.c_contiguous else A.ravel()
+    step = max(1, flat.size // 65536)
+    return _digest(np.ascontiguousarray(flat[::step]))
+
+
+def forget(H=None):
+    """Drop the cached decoder of H (all of them when H is None): call it after changing a large
+    matrix IN PLACE, which the identity fast path cannot notice."""
+    if H is None:
+        _DECODERS.clear()
+        _BY_ID.clear()
+        return
+    for k in [k for k in _BY_ID if k[0] == id(H)]:
+        _BY_ID.pop(k, None)
 
 
 def decoder_for(H, device=None) -> _lib.Decoder:
     """Decoder handle for H, cached on the matrix content (the reference re-derives the graph on
     every call; here that happens once per code).
+
+    Lookup: a read-only array, or a large one (see _FULL_HASH_LIMIT), that is the very object and
+    buffer seen before is trusted (large writeable ones after a sampled checksum); everything else is
+    hashed in full on every call, so an in-place change of a small matrix is always noticed.
 
     The cache only holds references: an evicted Decoder stays usable by whoever still holds it and
     its device handle is destroyed when the last reference goes (``Decoder.__del__``).  A handle is
@@ -90,10 +115,16 @@ def decoder_for(H, device=None) -> _lib.Decoder:
     except Exception:  # pragma: no cover
         sparse = False
     fp = _fingerprint(H, sparse)
-    if fp is not None:
+    big = fp is not None and H.nbytes > _FULL_HASH_LIMIT and not _STRICT
+    sample = None
+    if fp is not None and (big or not H.flags.writeable):
         hit = _BY_ID.get((id(H), device))
         if hit is not None and hit[0]() is H and hit[1] == fp and hit[2] in _DECODERS:
-            return _DECODERS[hit[2]]
+            if not H.flags.writeable:
+                return _DECODERS[hit[2]]
+            sample = _sample_digest(H)
+            if sample == hit[3]:
+                return _DECODERS[hit[2]]
     if sparse:
         S = H.tocsr()
         key = ("s", S.shape, _digest(np.ascontiguousarray(S.indptr)),
@@ -109,12 +140,14 @@ def decoder_for(H, device=None) -> _lib.Decoder:
         if len(_DECODERS) >= _MAX_CACHED:
             _DECODERS.pop(next(iter(_DECODERS)))       # drop the reference only (see docstring)
         _DECODERS[key] = dec
-    if fp is not None:
+    if fp is not None and (big or not H.flags.writeable):
         import weakref
         if len(_BY_ID) > 4 * _MAX_CACHED:
             _BY_ID.clear()
         try:
-            _BY_ID[(id(H), device)] = (weakref.ref(H), fp, key)
+            if big and H.flags.writeable and sample is None:
+                sample = _sample_digest(H)
+            _BY_ID[(id(H), device)] = (weakref.ref(H), fp, key, sample)
         except TypeError:  # pragma: no cover
             pass
     return dec

@@ -271,3 +271,45 @@ def test_self_launch_command_and_supervisor(tmp_path):
     r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, timeout=300, env=env)
     assert "rank 0 of 2" in r.stdout and "rank 1 of 2" in r.stdout
     assert r.returncode != 0          # a failing rank fails the supervisor
+
+
+def test_decoder_cache_lookup_rules(monkeypatch):
+    """qldpc_amd.bp.decoder_for without a device (Decoder stubbed): small matrices are re-hashed on every
+    call (an in-place change gives a new decoder); a large dense matrix that is the same object is
+    trusted after a sampled checksum, and `forget` drops it; eviction only drops the cache's reference."""
+    from qldpc_amd import _lib, bp
+    made = []
+
+    class Stub:
+        def __init__(self, row_ptr, col_idx, m, n, device):
+            made.append((m, n))
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(_lib, "Decoder", Stub)
+    bp.forget()
+    try:
+        big = np.zeros((600, 600), np.float64)                    # 2.9 MB: identity + sampled checksum
+        big[np.arange(600), np.arange(600)] = 1
+        d1 = bp.decoder_for(big)
+        assert bp.decoder_for(big) is d1 and len(made) == 1
+        bp.forget(big)
+        assert bp.decoder_for(big) is d1 and len(made) == 1       # same content: found again by its hash
+        big[5, 7] = 1
+        bp.forget(big)
+        assert bp.decoder_for(big) is not d1 and len(made) == 2
+        small = np.eye(20, dtype=np.int64)
+        e1 = bp.decoder_for(small)
+        small[0, 3] = 1                                           # in place: noticed without any call
+        assert bp.decoder_for(small) is not e1
+        ro = np.eye(30, dtype=np.int64)
+        ro.setflags(write=False)
+        r1 = bp.decoder_for(ro)
+        assert bp.decoder_for(ro) is r1
+        for k in range(20):                                       # more matrices than the cache holds
+            bp.decoder_for(np.eye(40 + k, dtype=np.int64))
+        assert not d1.closed and not e1.closed                    # evicted, never closed behind a holder's back
+    finally:
+        bp.forget()
