@@ -6,9 +6,11 @@ entry point raises (``QbpError``) instead of computing something else.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import importlib.util
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -116,8 +118,22 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def _locked(method):
+    """Serialise the host-buffer entry points of one Decoder: a qbp_handle owns one set of device
+    scratch buffers and one stream (include/qbp.h: "not thread-safe"), while the reference's
+    functions are pure and may be called from a thread pool.  ctypes drops the GIL during the call,
+    so without this two threads decoding the same matrix would share that scratch."""
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
 class Decoder:
-    """One parity-check matrix on one GPU (wraps a ``qbp_handle``)."""
+    """One parity-check matrix on one GPU (wraps a ``qbp_handle``).  Methods taking host arrays
+    are serialised per Decoder (thread-safe); the ``*_device`` methods only enqueue work on the
+    caller's stream and are ordered by the caller."""
 
     def __init__(self, row_ptr, col_idx, m, n, device=0):
         lib = load()
@@ -129,6 +145,7 @@ class Decoder:
                               int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self._lock = threading.RLock()
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -144,10 +161,12 @@ class Decoder:
     def info(self, what):
         return int(load().qbp_get_info(self._h, INFO[what]))
 
+    @_locked
     def set_option(self, option, value):
         _check(load().qbp_set_option(self._h, int(option), int(value)))
 
     # ---- host buffers ----------------------------------------------------------------------
+    @_locked
     def decode(self, syndromes, prior, max_iter=50, variant=SUM_PRODUCT, alpha=1.0, damping=1.0,
                clip_llr=20.0, flags=0, want_llr=True):
         syn = np.ascontiguousarray(syndromes, np.uint8)
@@ -179,6 +198,7 @@ class Decoder:
         """Trials one qbp_mc_run call may cover with FLAG_OSD0 (per-trial records: m + 10 n bytes)."""
         return max(1, min(MC_OSD_MAX_TRIALS, (8 << 30) // (self.m + 10 * self.n)))
 
+    @_locked
     def mc_run(self, Lx, distance, p, prior, trial_begin, trial_end, draws=1, seed=0, max_iter=50,
                variant=SUM_PRODUCT, alpha=1.0, damping=1.0, clip_llr=20.0, flags=0):
         Lx = np.ascontiguousarray(Lx, np.uint8)
@@ -206,6 +226,7 @@ class Decoder:
             int(trial_begin), int(trial_end), d_prior, int(max_iter), int(variant), float(alpha),
             float(damping), float(clip_llr), int(flags), d_counters, stream or None))
 
+    @_locked
     def check_messages(self, syndromes, prior, variant, alpha=1.0, damping=1.0, clip_llr=20.0,
                        iteration=0):
         """Check->variable messages float64[B, E] (CSR edge order) after iteration `iteration`."""
@@ -219,6 +240,7 @@ class Decoder:
                                          float(clip_llr), int(iteration), out.ctypes.data))
         return out
 
+    @_locked
     def message_histograms(self, syndromes, errors, prior, variant, alpha=1.0, damping=1.0,
                            clip_llr=20.0, iteration=0, bins=50):
         """(edges float64[bins + 1], hist0 int64[bins], hist1 int64[bins]): the check->variable
@@ -237,6 +259,7 @@ class Decoder:
                                              h0.ctypes.data, h1.ctypes.data))
         return edges, h0, h1
 
+    @_locked
     def osd0(self, syndromes, llr, hard):
         """OSD-0 on B decoder outputs (host arrays) -> solution uint8[B, n]."""
         syn = np.ascontiguousarray(syndromes, np.uint8)
@@ -256,12 +279,14 @@ class Decoder:
         _check(load().qbp_osd0_batch_device(self._h, d_syndromes, d_llr, d_hard, int(B), d_solution,
                                             stream or None))
 
+    @_locked
     def mc_sample_errors(self, p, trial_begin, T, draws=1, seed=0):
         out = np.empty((int(T), self.n), np.uint8)
         _check(load().qbp_mc_sample_errors(self._h, float(p), int(draws), int(seed),
                                            int(trial_begin), int(T), out.ctypes.data))
         return out
 
+    @_locked
     def debug_math(self, kind, x):
         x = np.ascontiguousarray(x, np.float64)
         y = np.empty_like(x)

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import threading
 
 import numpy as np
 
@@ -34,6 +35,7 @@ except Exception:  # pragma: no cover
 _DECODERS: dict = {}
 _BY_ID: dict = {}          # id(H) -> (weakref to H or None, fingerprint, key): skips the content hash
 _MAX_CACHED = 16
+_CACHE_LOCK = threading.RLock()   # the reference's functions are pure: callable from thread pools
 # HIP device used by the module-level functions (one process per GPU: set QBP_DEVICE per rank, or
 # assign qldpc_amd.bp.DEVICE before the first call)
 DEVICE = int(os.environ.get("QBP_DEVICE", "0"))
@@ -88,12 +90,13 @@ def _sample_digest(A):
 def forget(H=None):
     """Drop the cached decoder of H (all of them when H is None): call it after changing a large
     matrix IN PLACE, which the identity fast path cannot notice."""
-    if H is None:
-        _DECODERS.clear()
-        _BY_ID.clear()
-        return
-    for k in [k for k in _BY_ID if k[0] == id(H)]:
-        _BY_ID.pop(k, None)
+    with _CACHE_LOCK:
+        if H is None:
+            _DECODERS.clear()
+            _BY_ID.clear()
+            return
+        for k in [k for k in _BY_ID if k[0] == id(H)]:
+            _BY_ID.pop(k, None)
 
 
 def decoder_for(H, device=None) -> _lib.Decoder:
@@ -105,10 +108,15 @@ def decoder_for(H, device=None) -> _lib.Decoder:
     hashed in full on every call, so an in-place change of a small matrix is always noticed.
 
     The cache only holds references: an evicted Decoder stays usable by whoever still holds it and
-    its device handle is destroyed when the last reference goes (``Decoder.__del__``).  A handle is
-    not thread-safe (include/qbp.h): threads that decode the same matrix concurrently should each
-    build their own ``_lib.Decoder``; this cache hands every caller the same one."""
-    device = DEVICE if device is None else device
+    its device handle is destroyed when the last reference goes (``Decoder.__del__``).  Every
+    caller gets the same Decoder; its host-array methods are serialised (``_lib._locked``), so the
+    module-level functions may be called from several threads -- threads that want to decode the
+    same matrix CONCURRENTLY should each build their own ``_lib.Decoder``."""
+    with _CACHE_LOCK:
+        return _decoder_for(H, DEVICE if device is None else device)
+
+
+def _decoder_for(H, device):
     try:
         from scipy.sparse import issparse
         sparse = issparse(H)

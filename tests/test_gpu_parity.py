@@ -379,3 +379,35 @@ def test_distinct_handles_from_concurrent_threads():
         for x, y in zip(got[i], want[i]):
             assert np.array_equal(x, y)
         assert np.array_equal(got_mc[i], want_mc[i])
+
+
+def test_module_functions_from_a_thread_pool():
+    """The reference's functions are pure, so callers may run them from a thread pool: the cached
+    Decoder of a matrix is shared by all threads and its host-array methods are serialised
+    (qldpc_amd/_lib.py: _locked).  Eight threads decode interleaved batches and single syndromes
+    of the SAME matrix through the module-level functions; results equal the serial ones."""
+    from concurrent.futures import ThreadPoolExecutor
+    from qldpc_amd import osd
+    code = codes.load_code("[[144, 12, 12]]")
+    H = code.Hx
+    rng = np.random.default_rng(77)
+    prior = mc.prior_of(0.05, code.n)
+    jobs = [((rng.random((400 + 37 * i, code.n)) < 0.05).astype(np.int64) @ H.T % 2) for i in range(8)]
+    want = [bp.performBeliefPropagationBatch(H, s, prior, 50) for s in jobs]
+
+    def work(i):
+        out = None
+        for _ in range(3):
+            out = bp.performBeliefPropagationBatch(H, jobs[i], prior, 50)
+            d, ok, llr = bp.performBeliefPropagationFast(H, jobs[i][0], prior, verbose=False, maxIter=50)
+            assert np.array_equal(d, out[0][0]) and ok == out[1][0] and np.array_equal(llr, out[2][0])
+            if not ok:
+                fixed = osd.performOSD(H, jobs[i][0], llr, d)
+                assert np.array_equal(fixed @ H.T % 2, jobs[i][0])
+        return out
+
+    with ThreadPoolExecutor(8) as pool:
+        got = list(pool.map(work, range(8)))
+    for g, w in zip(got, want):
+        for x, y in zip(g, w):
+            assert np.array_equal(x, y)

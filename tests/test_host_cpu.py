@@ -313,3 +313,38 @@ def test_decoder_cache_lookup_rules(monkeypatch):
         assert not d1.closed and not e1.closed                    # evicted, never closed behind a holder's back
     finally:
         bp.forget()
+
+
+def test_host_array_methods_of_a_decoder_are_serialised():
+    """The reference's functions are pure (callable from a thread pool); a qbp_handle is not
+    thread-safe.  Every Decoder method that takes host arrays runs under the Decoder's lock, the
+    cache lookup under the cache's (no device needed: the lock is observed through a stub)."""
+    import threading
+    from qldpc_amd import _lib, bp
+    for name in ("decode", "mc_run", "check_messages", "message_histograms", "osd0",
+                 "mc_sample_errors", "debug_math", "set_option"):
+        assert getattr(_lib.Decoder, name).__wrapped__ is not None, name
+    for name in ("decode_device", "mc_run_device", "osd0_device"):     # enqueue only: caller-ordered
+        assert not hasattr(getattr(_lib.Decoder, name), "__wrapped__"), name
+
+    inside, overlaps = [0], [0]
+
+    class Fake:
+        _lock = threading.RLock()
+
+        @_lib._locked
+        def call(self):
+            inside[0] += 1
+            if inside[0] > 1:
+                overlaps[0] += 1
+            threading.Event().wait(0.002)
+            inside[0] -= 1
+
+    f = Fake()
+    ts = [threading.Thread(target=lambda: [f.call() for _ in range(5)]) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert overlaps[0] == 0
+    assert isinstance(bp._CACHE_LOCK, type(threading.RLock()))
