@@ -465,6 +465,22 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     if ((flags & QBP_FLAG_PAIRWISE_COLSUM) && h->max_col_deg > qbp::GENERIC_PAIRWISE_MAX_COL)
         return fail(QBP_E_UNSUPPORTED, "QBP_FLAG_PAIRWISE_COLSUM supports column weights up to %d (got %d)",
                     qbp::GENERIC_PAIRWISE_MAX_COL, h->max_col_deg);
+    // one launch hands out its syndromes through a 32-bit counter
+    constexpr int64_t MAX_LAUNCH = (int64_t)1 << 30;
+    if (B > MAX_LAUNCH) {
+        if (!mc)
+            return fail(QBP_E_UNSUPPORTED, "the general-H kernel decodes at most 2^30 syndromes per call (got %lld)",
+                        (long long)B);
+        for (int64_t off = 0; off < B; off += MAX_LAUNCH) {     // Monte-Carlo: trial ranges of any length
+            qbp::GenericParams part = *mc;
+            part.trial_begin += off;
+            const int rc = generic_launch(h, nullptr, d_prior, std::min(MAX_LAUNCH, B - off), max_iter, variant,
+                                          alpha, damping, clip_llr, flags, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, 0, 1.0, s, &part);
+            if (rc) return rc;
+        }
+        return QBP_OK;
+    }
     const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
     const GenericGeom g = generic_geometry(h, B);
     if (g.lds > (size_t)160 * 1024)
@@ -500,6 +516,9 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
     G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
     G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p;
+    G.work_counter = h->d_work_counter.p;
+    if (B > (int64_t)g.grid)     // (else every index it can yield is >= B whatever it holds)
+        HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
     G.dump_R = d_dump; G.dump_iter = dump_iter; G.dump_div = dump_div;
     h->last_threads = g.threads; h->last_lds = (int)g.lds; h->last_grid = g.grid;
     if (mc) {

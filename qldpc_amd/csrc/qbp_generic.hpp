@@ -61,6 +61,7 @@ struct GenericParams {
     int rpad_off[GENERIC_MAX_ROW_CLASS + 2];
     const int32_t* long_edge_row;   // [E - row_base[9]]
     double* wsL;                // [grid][3 * number of long checks] row product / (sprod, min1, min2)
+    unsigned long long* work_counter;   // zeroed before launch: index - grid of the next undecoded syndrome
     // ---- variables, sorted by column weight (stable): sorted position x -> variable svar[x] ----
     // vpos / vrow hold, per column entry, the message position and the SORTED position of the
     // entry's check, in the same blocked-transposed arrangement: entry j (ascending check) of the
@@ -121,7 +122,7 @@ struct GenericParams {
 __host__ __device__ inline size_t generic_lds_words(int m)
 {
     const size_t mw = ((size_t)m + 31) >> 5;
-    return (((3 * mw + 2 + 1) & ~(size_t)1) + 4 + NUM_COUNTERS + 1) & ~(size_t)1;
+    return (((3 * mw + 2 + 1) & ~(size_t)1) + 4 + NUM_COUNTERS + 2 + 1) & ~(size_t)1;
 }
 __host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool lds_msgs, bool lds_tables,
                                                     int r_split = 0)
@@ -307,6 +308,8 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
     int* const mc_weight = reinterpret_cast<int*>(words + acc_off + 2);
     int* const mc_diff = mc_weight + 1;
     int* const mc_cnt = mc_diff + 1;                // [NUM_COUNTERS] this workgroup's counter row (MC)
+    // index (minus gridDim.x) of the workgroup's next syndrome, drawn from the launch's work counter
+    unsigned* const next_item = reinterpret_cast<unsigned*>(mc_cnt + NUM_COUNTERS);
     // tables of the variable step: from LDS when the launch reserved room for them, else from L2
     const double* prior_t = P.prior_sorted;
     const int32_t* vpos_t = P.vpos;
@@ -348,9 +351,23 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         }
     };
 
-    for (long long b = blockIdx.x; b < P.B; b += gridDim.x) {
+    // Work distribution: the first syndrome of a workgroup is static, the following ones come from a
+    // global counter (syndromes differ widely in iterations with early exit: a static stride leaves
+    // the workgroups that drew the slow ones running alone at the end).  Thread 0 issues the atomic
+    // when a syndrome starts and hands the result over when it ends, so its latency is never waited for.
+    // (32 bits: one register instead of two across the whole decode; the host keeps a launch below
+    // 2^31.  The split-R build has no register to spare and milliseconds per syndrome: it fetches at
+    // the end and waits the microsecond.)
+    constexpr bool EARLY_FETCH = MEM != GENERIC_MEM_SPLIT;
+    const bool dynamic = P.B > (long long)gridDim.x;      // else every syndrome is a workgroup's first
+    unsigned fetched = 0x7fffffffu;
+    for (long long b = blockIdx.x; b < P.B;) {
         const uint8_t* const syn = MC ? nullptr : P.syndromes + b * m;
-        if (tid == 0) unsat[0] = 0;
+        if (tid == 0) {
+            unsat[0] = 0;
+            if constexpr (EARLY_FETCH)
+                if (dynamic) fetched = atomicAdd(reinterpret_cast<unsigned*>(P.work_counter), 1u);
+        }
         if constexpr (MC) {
             // errors of trial trial_begin + b: one Philox evaluation per four qubits
             // (beliefPropagationGPU.py:195)
@@ -664,7 +681,13 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 __syncthreads();     // emission read R; the next check step overwrites it
             }
         }
+        if (tid == 0) {
+            if constexpr (!EARLY_FETCH)
+                if (dynamic) fetched = atomicAdd(reinterpret_cast<unsigned*>(P.work_counter), 1u);
+            *next_item = fetched;
+        }
         __syncthreads();
+        b = (long long)gridDim.x + (long long)*next_item;   // (next write: after the barrier at the loop top)
     }
     if constexpr (MC) {
         if (tid == 0)

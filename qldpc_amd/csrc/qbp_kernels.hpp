@@ -46,6 +46,9 @@
 #ifndef QBP_MC_PACK
 #define QBP_MC_PACK 0
 #endif
+#ifndef QBP_WORK_CHUNK_POLICY
+#define QBP_WORK_CHUNK_POLICY 2   // syndromes per fetch from the work counter: see "Work distribution"
+#endif
 
 namespace qbp {
 
@@ -107,6 +110,13 @@ __device__ __forceinline__ ColdArgs cold_args()
     return p;
 }
 #define COLD(field) (cold_args()->field)
+
+// Syndromes a slot leader fetches at once after a syndrome that finished at 0-based iteration `it`
+// (see "Work distribution" in the kernel).
+__device__ __forceinline__ int work_chunk_after(int it)
+{
+    return it < 3 ? 8 : it < 7 ? 4 : it < 15 ? 2 : 1;
+}
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi)
 {   // np.clip(x, lo, hi) == minimum(maximum(x, lo), hi) for non-NaN x: v_max_f64 + v_min_f64
@@ -223,10 +233,20 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     const int max_iter = P.max_iter;
 
     // Work distribution: the first syndrome of a slot is static; afterwards the slot leader draws
-    // chunks of WORK_CHUNK consecutive indices from one global counter (one returning atomic per
-    // WORK_CHUNK syndromes: a single word sustains only ~88 dequeues/us, MI355X_MICROARCH.md
-    // 'dequeue', which early-exit decoding at low error rates would exceed).
-    constexpr int WORK_CHUNK = FORCE_FULL ? 1 : 8;   // forced mode: 1 atomic per max_iter iterations
+    // chunks of consecutive indices from one global counter.  A single word sustains only ~88
+    // dequeues/us (MI355X_MICROARCH.md 'dequeue'), which early-exit decoding at low error rates
+    // would exceed with one atomic per syndrome -- and a chunk of eight syndromes that all run
+    // max_iter iterations is a 8 x max_iter iteration tail on one slot while others idle (the
+    // reference driver's 5 000-syndrome batches at p = 0.05, maxIter 150: 3.8 ms instead of 1.7).
+    // So, once fewer than 8 syndromes per slot are left to hand out (small batches: from the start),
+    // the chunk follows the work: 8 after a syndrome that took < 4 iterations, 4 / 2 below 8 / 16,
+    // else 1 (work_chunk_after) -- at most one atomic per ~16 iterations per slot; before that the
+    // chunk is 8 (every slot will be back for more: no tail to protect).
+    auto work_chunk = [&](long long handed_out, int suggested) -> int {
+        if (QBP_WORK_CHUNK_POLICY == 0) return FORCE_FULL ? 1 : 8;                 // (A/B: round 1's rule)
+        if (QBP_WORK_CHUNK_POLICY == 2 && B - handed_out > 8 * total_slots) return 8;
+        return suggested;
+    };
     long long b = lane_valid ? (long long)blockIdx.x * S + slot : B;
     bool active = b < B;
 
@@ -240,9 +260,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         if constexpr (MC) {
             for (int i = 0; i < NUM_COUNTERS; ++i) mc_count[i] = 0;
         }
-        const long long first = total_slots + (long long)atomicAdd(P.work_counter, (unsigned long long)WORK_CHUNK);
+        // (a launch whose syndromes are all some slot's first one never touches the counter: tens of
+        // thousands of atomics on one word in the same microsecond are not free -- 40 us for 10 000)
+        const int ch = work_chunk(total_slots, 1);
+        const long long first =
+            B > total_slots ? total_slots + (long long)atomicAdd(P.work_counter, (unsigned long long)ch) : B;
         next_work[slot] = first;
-        chunk_ends[slot] = first + WORK_CHUNK;
+        chunk_ends[slot] = first + ch;
     }
     if (tid == 0) {
         long long first = (long long)blockIdx.x * S;
@@ -286,8 +310,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     bool need_start = active;     // (re)initialise at the loop top, where Q / val / R are dead
     __syncthreads();
 
-    // leader-only bookkeeping
-    bool refill = false;
+    // leader-only bookkeeping (refill: 0, or the size of the next chunk should one be needed)
+    int refill = 0;
     bool mc_pending = false;
     int mc_pending_conv = 0, mc_pending_it = 0;
 
@@ -431,12 +455,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             if (refill) {
                 long long nx = next_work[slot] + 1;
                 if (nx == chunk_ends[slot]) {
+                    const int ch = work_chunk(nx, refill);
                     nx = total_slots +
-                         (long long)atomicAdd(COLD(work_counter), (unsigned long long)WORK_CHUNK);
-                    chunk_ends[slot] = nx + WORK_CHUNK;
+                         (long long)atomicAdd(COLD(work_counter), (unsigned long long)ch);
+                    chunk_ends[slot] = nx + ch;
                 }
                 next_work[slot] = nx;
-                refill = false;
+                refill = 0;
             }
             if constexpr (MC) {
                 if (mc_pending) {
@@ -547,10 +572,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             const bool finished = last || (conv && !FORCE_FULL);
             if (finished) {
                 b = next_work[slot];
-                if (c == 0) refill = true;
                 if (b < B) {
                     need_start = true;
-                } else {
+                    if (c == 0) refill = FORCE_FULL ? 1 : work_chunk_after(it);   // (the counter only grows:
+                } else {                                                          //  past B, nothing to fetch)
                     active = false;
                     if (c == 0) atomicSub(active_count, 1);
                 }
