@@ -174,7 +174,7 @@ size_t fused_lds_bytes(int dc, int m, int n, int S)
 {
     const size_t slot_stride = (size_t)dc * m + 2;
     size_t lds = ((size_t)S * slot_stride + (size_t)dc * m + 3 * (size_t)S) * 8 +
-                 (4 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
+                 (5 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
                  2 * (size_t)S * (((size_t)n + 3) / 4) * 4;     // err_lds[2][S][n4] (Monte-Carlo builds)
     return (lds + 15) & ~(size_t)15;
 }

@@ -46,8 +46,8 @@
 #ifndef QBP_MC_PACK
 #define QBP_MC_PACK 0
 #endif
-#ifndef QBP_WORK_CHUNK_POLICY
-#define QBP_WORK_CHUNK_POLICY 2   // syndromes per fetch from the work counter: see "Work distribution"
+#ifndef QBP_WORK_CHUNK_FIXED
+#define QBP_WORK_CHUNK_FIXED 0    // 1: eight syndromes per fetch from the work counter, always (A/B)
 #endif
 
 namespace qbp {
@@ -111,11 +111,11 @@ __device__ __forceinline__ ColdArgs cold_args()
 }
 #define COLD(field) (cold_args()->field)
 
-// Syndromes a slot leader fetches at once after a syndrome that finished at 0-based iteration `it`
+// Syndromes a slot leader fetches at once when its syndromes have taken avg4 / 4 iterations on average
 // (see "Work distribution" in the kernel).
-__device__ __forceinline__ int work_chunk_after(int it)
+__device__ __forceinline__ int work_chunk_for(int avg4)
 {
-    return it < 3 ? 8 : it < 7 ? 4 : it < 15 ? 2 : 1;
+    return avg4 < 12 ? 8 : avg4 < 28 ? 4 : avg4 < 60 ? 2 : 1;
 }
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi)
@@ -181,9 +181,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     int* const flag0 = words;            // [2][S]
     int* const mc_weight = words + 2 * S;
     int* const mc_diff = words + 3 * S;
-    int* const active_count = words + 4 * S;
-    int* const mc_count = words + 4 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
-    int* const var_lds = words + 4 * S + 1 + S * NUM_COUNTERS;     // [DC][m], -1 = padding
+    int* const work_avg = words + 4 * S;     // [0]: 4 x running mean of the workgroup's iterations per syndrome ([S] reserved)
+    int* const active_count = words + 5 * S;
+    int* const mc_count = words + 5 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
+    int* const var_lds = words + 5 * S + 1 + S * NUM_COUNTERS;     // [DC][m], -1 = padding
     // Monte-Carlo mode: sampled error bytes of the slot's trials, [2][S][n4] (n4 = n rounded up to a
     // multiple of 4), written by the slot's first ceil(n/4) lanes one barrier before use.  Two
     // buffers per slot, used alternately by consecutive trials: the emission of a finished trial still
@@ -237,15 +238,20 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // dequeues/us (MI355X_MICROARCH.md 'dequeue'), which early-exit decoding at low error rates
     // would exceed with one atomic per syndrome -- and a chunk of eight syndromes that all run
     // max_iter iterations is a 8 x max_iter iteration tail on one slot while others idle (the
-    // reference driver's 5 000-syndrome batches at p = 0.05, maxIter 150: 3.8 ms instead of 1.7).
-    // So, once fewer than 8 syndromes per slot are left to hand out (small batches: from the start),
-    // the chunk follows the work: 8 after a syndrome that took < 4 iterations, 4 / 2 below 8 / 16,
-    // else 1 (work_chunk_after) -- at most one atomic per ~16 iterations per slot; before that the
-    // chunk is 8 (every slot will be back for more: no tail to protect).
-    auto work_chunk = [&](long long handed_out, int suggested) -> int {
-        if (QBP_WORK_CHUNK_POLICY == 0) return FORCE_FULL ? 1 : 8;                 // (A/B: round 1's rule)
-        if (QBP_WORK_CHUNK_POLICY == 2 && B - handed_out > 8 * total_slots) return 8;
-        return suggested;
+    // reference driver's 5 000-syndrome batches at p = 0.05, maxIter 150: 3.5 ms instead of 2.05).
+    // Chunk = the larger of
+    //   * a share of what is left: 8 / 4 / 2 / 1 syndromes while >= 16 / 8 / 4 / 0 per slot remain
+    //     (judged by the slot's own last index: the counter may be a chunk per slot further), and
+    //   * what the workgroup's recent syndromes cost: 8 while they took < 3 iterations on average,
+    //     4 / 2 below 7 / 15, else 1 (work_chunk_for).  That running mean starts at max_iter, jumps
+    //     up with one slow syndrome and decays by a quarter per finished one: the first syndromes
+    //     to finish are the easy ones, and must not earn a slot eight hard ones.
+    // Measured against a fixed chunk of 8 and three other rules: profiles/r02_ab_work_chunk.txt.
+    auto work_chunk = [&](long long handed_out, int by_cost) -> int {
+        if (QBP_WORK_CHUNK_FIXED) return FORCE_FULL ? 1 : 8;                       // (A/B: round 1's rule)
+        const long long rem = B - handed_out;
+        const int share = rem >= 16 * total_slots ? 8 : rem >= 8 * total_slots ? 4 : rem >= 4 * total_slots ? 2 : 1;
+        return share > by_cost ? share : by_cost;
     };
     long long b = lane_valid ? (long long)blockIdx.x * S + slot : B;
     bool active = b < B;
@@ -257,12 +263,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         mc_lmask[slot] = 0ull;
         mc_weight[slot] = 0;
         mc_diff[slot] = 0;
+        if (slot == 0) *work_avg = 4 * P.max_iter;
         if constexpr (MC) {
             for (int i = 0; i < NUM_COUNTERS; ++i) mc_count[i] = 0;
         }
         // (a launch whose syndromes are all some slot's first one never touches the counter: tens of
         // thousands of atomics on one word in the same microsecond are not free -- 40 us for 10 000)
-        const int ch = work_chunk(total_slots, 1);
+        const int ch = work_chunk(9 * total_slots, 1);      // (every slot fetches at this moment)
         const long long first =
             B > total_slots ? total_slots + (long long)atomicAdd(P.work_counter, (unsigned long long)ch) : B;
         next_work[slot] = first;
@@ -574,8 +581,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 b = next_work[slot];
                 if (b < B) {
                     need_start = true;
-                    if (c == 0) refill = FORCE_FULL ? 1 : work_chunk_after(it);   // (the counter only grows:
-                } else {                                                          //  past B, nothing to fetch)
+                    if (c == 0) {                  // (the counter only grows: past B, nothing to fetch)
+                        if constexpr (FORCE_FULL) {
+                            refill = 1;
+                        } else {
+                            // (shared by the slot leaders of the workgroup: a lost update is harmless)
+                            const int a4 = *work_avg;
+                            const int n4 = it * 4 > a4 ? it * 4 : a4 - (a4 >> 2) + it;
+                            *work_avg = n4;
+                            refill = work_chunk_for(n4);
+                        }
+                    }
+                } else {
                     active = false;
                     if (c == 0) atomicSub(active_count, 1);
                 }
