@@ -256,8 +256,20 @@ def generate_errors_and_syndromes_batch(H, error_rate, batch_size, rng=None):
     H = np.asarray(H)
     num_vars = H.shape[1]
     errors = (rng.random((batch_size, num_vars)) < error_rate).astype(np.int8)
-    syndromes = (errors @ H.T) % 2
-    return errors, syndromes.astype(np.int8)
+    return errors, _syndromes_of(errors, H)
+
+
+def _syndromes_of(errors, H):
+    """``((errors @ H.T) % 2).astype(np.int8)`` (:198-200).  numpy multiplies integer matrices with a
+    scalar loop over all m n entries (int8 x int64, 5 000 x 288 x 144: 0.16 s -- fifty times the
+    decode of that batch); for an integer or bool H the same integer product over the non-zeros of H
+    only (scipy CSR: 5 ms) has the same parity -- exactly: integer arithmetic, and a wrap-around of
+    the reference's narrower accumulator (int8 for a bool H) never changes a parity."""
+    if H.dtype.kind in "iub":
+        from scipy.sparse import csr_matrix
+        sums = np.asarray(errors @ csr_matrix(H.T.astype(np.int64)))
+        return (sums & 1).astype(np.int8)
+    return ((errors @ H.T) % 2).astype(np.int8)
 
 
 def gpu_available() -> bool:

@@ -348,3 +348,26 @@ def test_host_array_methods_of_a_decoder_are_serialised():
         t.join()
     assert overlaps[0] == 0
     assert isinstance(bp._CACHE_LOCK, type(threading.RLock()))
+
+
+def test_sampler_mirror_matches_the_reference_formula():
+    """generate_errors_and_syndromes_batch (beliefPropagationGPU.py:181-200): same random stream, and the
+    syndromes of the sparse integer product equal ((errors @ H.T) % 2).astype(int8) for every dtype of H
+    the reference's formula accepts -- including where its narrow accumulators wrap around."""
+    from qldpc_amd import bp, codes
+    H = codes.load_code("[[144, 12, 12]]").Hx
+    e, s = bp.generate_errors_and_syndromes_batch(H, 0.07, 500, np.random.default_rng(5))
+    rng = np.random.default_rng(5)
+    e_ref = (rng.random((500, H.shape[1])) < 0.07).astype(np.int8)
+    assert e.dtype == np.int8 and s.dtype == np.int8
+    assert np.array_equal(e, e_ref) and np.array_equal(s, ((e_ref @ H.T) % 2).astype(np.int8))
+    rng = np.random.default_rng(6)
+    for dt in (bool, np.int8, np.uint8, np.int32, np.int64, np.uint64, np.float64):
+        if dt is bool:
+            Hx = rng.integers(0, 2, (30, 300)).astype(dt)       # dense: int8 sums wrap in the reference
+        elif dt in (np.uint8, np.uint64):
+            Hx = rng.integers(0, 200, (30, 300)).astype(dt)
+        else:
+            Hx = rng.integers(-100, 100, (30, 300)).astype(dt)
+        err = (rng.random((200, 300)) < 0.6).astype(np.int8)
+        assert np.array_equal(bp._syndromes_of(err, Hx), ((err @ Hx.T) % 2).astype(np.int8)), dt
