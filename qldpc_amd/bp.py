@@ -169,7 +169,7 @@ def _syndromes(s, m, batch):
     want = 2 if batch else 1
     if a.ndim != want or a.shape[-1] != m:
         raise ValueError(f"syndrome has shape {a.shape}, expected {'(B, ' if batch else '('}{m})")
-    if ((a != 0) & (a != 1)).any():
+    if (a.view(np.uint8) > 1).any():            # (int8: negative values are > 1 as bytes)
         raise ValueError("syndrome entries must be 0 or 1")
     return a
 
@@ -196,7 +196,7 @@ def decode_one(H, syndrome, initialBelief, maxIter, variant=_lib.SUM_PRODUCT, al
     """(hard int8[n], converged bool, llr float64[n], iteration int) for one syndrome."""
     dec = decoder_for(H)
     syn = _syndromes(syndrome, dec.m, batch=False)
-    hard, conv, iters, llr = dec.decode(syn[None, :].astype(np.uint8), _prior(initialBelief, dec.n),
+    hard, conv, iters, llr = dec.decode(syn[None, :].view(np.uint8), _prior(initialBelief, dec.n),
                                         _check_iter(maxIter), variant, alpha, damping, clip_llr, flags)
     return hard[0].astype(np.int8), bool(conv[0]), llr[0], int(iters[0])
 
@@ -242,9 +242,9 @@ def performBeliefPropagationBatch(H, syndromes, initialBelief, maxIter=50):
     """decoding/beliefPropagationGPU.py:81-178 -> (int8[B, n], bool[B], float64[B, n])."""
     dec = decoder_for(H)
     syn = _syndromes(syndromes, dec.m, batch=True)
-    hard, conv, _, llr = dec.decode(syn.astype(np.uint8), _prior(initialBelief, dec.n),
+    hard, conv, _, llr = dec.decode(syn.view(np.uint8), _prior(initialBelief, dec.n),
                                     _check_iter(maxIter))
-    return hard.astype(np.int8), conv, llr
+    return hard.view(np.int8), conv, llr       # (0/1 bytes of a fresh array: no copy)
 
 
 def generate_errors_and_syndromes_batch(H, error_rate, batch_size, rng=None):

@@ -887,7 +887,10 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
                 }
                 h->stage_bytes = STAGE;
             }
-            const size_t chunk = std::max<size_t>(1, std::min<size_t>(b, STAGE / (per + 8)));
+            // (pieces of at least 1 MiB, at least four of them above 4 MiB: the reference driver's 13 MB per
+            // batch then overlap their DMA with the copy-out instead of running one after the other)
+            const size_t quarter = std::max<size_t>((b + 3) / 4, ((size_t)1 << 20) / per + 1);
+            const size_t chunk = std::max<size_t>(1, std::min<size_t>({b, STAGE / (per + 8), quarter}));
             struct Piece { size_t b0, cnt; };
             Piece prev{0, 0};
             auto offsets = [&](size_t cnt, size_t& o_llr, size_t& o_it, size_t& o_hard, size_t& o_conv) {
