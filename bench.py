@@ -534,7 +534,8 @@ def dropin_leg(code, device, p=0.05, batch=5000, batches=4, max_iter=150):
                                            "trials_per_s_1M_trials": Tbig / t_mc_big,
                                            "ler": int(c[1]) / T},
             "note": "host-array signature: H2D of syndromes and D2H of hard/converged/LLR (8n bytes per trial) "
-                    "inside the timed call"}
+                    "inside the timed call; the per-failure performOSD calls are rows of the last batch and are "
+                    "served from one batched OSD launch per batch (qldpc_amd/osd.py::_from_last_batch)"}
 
 
 if __name__ == "__main__":

@@ -238,13 +238,40 @@ def performBeliefPropagationGPU(H, syndrome, initialBelief, verbose=False, maxIt
     return hard, conv, llr
 
 
+class _LastBatch:
+    """What `performOSD` needs to serve the reference driver's loop (paperResults_GPU.py:113-123: one
+    OSD call per sample BP did not converge on, with rows of the arrays returned below) from ONE
+    batched OSD launch: see qldpc_amd/osd.py.  Holds the syndromes (the shim's own int8 copy or the
+    caller's int8 array), the returned arrays (so their memory cannot be recycled while rows are
+    recognised by address; batches above _LAST_BATCH_LIMIT bytes of LLRs are not remembered) and --
+    once the first such call arrives -- the gathered inputs and solutions of all failing rows."""
+    __slots__ = ("dec", "syn", "llr", "hard", "conv", "addr", "rowbytes", "rows", "pos", "inputs",
+                 "solutions", "lock")
+
+    def __init__(self, dec, syn, llr, hard, conv):
+        self.dec, self.syn, self.conv = dec, syn, conv.copy()
+        self.llr, self.hard = llr, hard
+        self.addr = llr.__array_interface__["data"][0]
+        self.rowbytes, self.rows = llr.strides[0], llr.shape[0]
+        self.pos = self.inputs = self.solutions = None
+        self.lock = threading.Lock()
+
+
+_LAST_BATCH = None
+_LAST_BATCH_LIMIT = 256 << 20
+
+
 def performBeliefPropagationBatch(H, syndromes, initialBelief, maxIter=50):
     """decoding/beliefPropagationGPU.py:81-178 -> (int8[B, n], bool[B], float64[B, n])."""
+    global _LAST_BATCH
     dec = decoder_for(H)
     syn = _syndromes(syndromes, dec.m, batch=True)
     hard, conv, _, llr = dec.decode(syn.view(np.uint8), _prior(initialBelief, dec.n),
                                     _check_iter(maxIter))
-    return hard.view(np.int8), conv, llr       # (0/1 bytes of a fresh array: no copy)
+    hard = hard.view(np.int8)                   # (0/1 bytes of a fresh array: no copy)
+    keep = 1 < len(conv) and llr.nbytes <= _LAST_BATCH_LIMIT and not conv.all()
+    _LAST_BATCH = _LastBatch(dec, syn, llr, hard, conv) if keep else None
+    return hard, conv, llr
 
 
 def generate_errors_and_syndromes_batch(H, error_rate, batch_size, rng=None):

@@ -15,7 +15,40 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import bp
 from .bp import decoder_for
+
+
+def _from_last_batch(dec, syn, l, hd):
+    """The reference driver calls performOSD once per sample its batch decode did not converge on,
+    with rows of the arrays that decode returned (paperResults_GPU.py:113-123): 3 450 launches of
+    240 us for a batch that took 3 ms to decode.  The first such call runs OSD-0 for ALL failing rows of
+    that batch in one launch; this and the following calls are then answered from its output -- after
+    checking that the arguments still hold exactly the values the solution was computed from (OSD is a
+    pure function of them).  Anything else (other arrays, changed contents, converged rows) returns None
+    and takes the one-syndrome path."""
+    lb = bp._LAST_BATCH
+    if lb is None or lb.dec is not dec or not isinstance(l, np.ndarray) or not l.flags.c_contiguous:
+        return None
+    off = l.__array_interface__["data"][0] - lb.addr
+    if off < 0 or off % lb.rowbytes or off // lb.rowbytes >= lb.rows:
+        return None
+    L, Hd = lb.llr, lb.hard
+    with lb.lock:
+        if lb.solutions is None:
+            idx = np.flatnonzero(~lb.conv)
+            inputs = (np.ascontiguousarray(lb.syn[idx]).view(np.uint8), L[idx], Hd[idx].view(np.uint8))
+            lb.solutions = dec.osd0(*inputs)
+            lb.inputs = inputs
+            lb.pos = np.full(lb.rows, -1, np.int64)
+            lb.pos[idx] = np.arange(len(idx))
+    k = lb.pos[off // lb.rowbytes]
+    if k < 0:
+        return None
+    s_in, l_in, h_in = lb.inputs
+    if not (np.array_equal(l, l_in[k]) and np.array_equal(hd, h_in[k]) and np.array_equal(syn, s_in[k])):
+        return None
+    return lb.solutions[k].astype(np.int64)
 
 
 def performOSD(H, syndrome, llr, hard):
@@ -25,6 +58,9 @@ def performOSD(H, syndrome, llr, hard):
     l = np.asarray(llr, dtype=np.float64)
     if syn.shape != (dec.m,) or hd.shape != (dec.n,) or l.shape != (dec.n,):
         raise ValueError(f"expected syndrome ({dec.m},), llr ({dec.n},), hard ({dec.n},)")
+    sol = _from_last_batch(dec, syn, l, hd)
+    if sol is not None:
+        return sol
     return dec.osd0(syn[None, :], l[None, :], hd[None, :])[0].astype(np.int64)
 
 

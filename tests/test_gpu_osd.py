@@ -240,3 +240,37 @@ def test_mc_osd_counters_trial_for_trial(name, p, T):
     print(dict(zip(_lib.COUNTER_NAMES, got.tolist())), "BP failures:", int((~conv).sum()))
     assert (~conv).sum() > 100
     assert np.array_equal(got, want), (got, want)
+
+
+def test_driver_loop_through_the_dropin_equals_single_calls():
+    """paperResults_GPU.py:108-123 through the drop-in: performBeliefPropagationBatch on 1 500 syndromes
+    (two draws at p = 0.05), then performOSD_enhanced(code, syndromes[i], llrs_batch[i], detections[i],
+    order=7) for every sample BP left unconverged.  The loop is served from one batched OSD launch
+    (qldpc_amd/osd.py::_from_last_batch); its outputs must equal the one-syndrome calls made on copies of
+    the same rows (which cannot be recognised as rows of the batch), and the CPU oracle."""
+    code = codes.load_code("[[144, 12, 12]]")
+    H = code.Hx
+    rng = np.random.default_rng(21)
+    p = 0.05
+    prior = [np.log((1 - p) / p)] * code.n
+    e1, s1 = bp.generate_errors_and_syndromes_batch(H, p, 1500, rng)
+    e2, s2 = bp.generate_errors_and_syndromes_batch(H, p, 1500, rng)
+    syndromes = (s1 + s2) % 2
+    detections, converged, llrs_batch = bp.performBeliefPropagationBatch(H, syndromes, prior, maxIter=150)
+    fails = np.flatnonzero(~converged)
+    assert len(fails) > 100
+    dec = bp.decoder_for(H)
+    before = None
+    got = {}
+    for i in fails:
+        got[int(i)] = osd.performOSD_enhanced(H, syndromes[i], llrs_batch[i], detections[i], order=7)
+        if before is None:
+            before = bp._LAST_BATCH.solutions
+            assert before is not None and len(before) == len(fails)
+    assert bp._LAST_BATCH.solutions is before                  # computed once
+    for i in fails[::7]:
+        single = osd.performOSD(H, syndromes[i].copy(), llrs_batch[i].copy(), detections[i].copy())
+        assert got[int(i)].dtype == np.int64 and np.array_equal(got[int(i)], single)
+        assert np.array_equal(got[int(i)] @ H.T % 2, syndromes[i])
+    for i in fails[::11]:
+        assert np.array_equal(got[int(i)], oracle.osd0(H, syndromes[i], llrs_batch[i], detections[i]))

@@ -371,3 +371,62 @@ def test_sampler_mirror_matches_the_reference_formula():
             Hx = rng.integers(-100, 100, (30, 300)).astype(dt)
         err = (rng.random((200, 300)) < 0.6).astype(np.int8)
         assert np.array_equal(bp._syndromes_of(err, Hx), ((err @ Hx.T) % 2).astype(np.int8)), dt
+
+
+def test_performOSD_serves_the_driver_loop_from_one_batched_call(monkeypatch):
+    """qldpc_amd/osd.py::_from_last_batch without a device: after a batch decode, performOSD on rows of
+    the returned arrays (the reference driver's loop) runs ONE osd0 call for all failing rows; changed
+    contents, copies, converged rows and other matrices take the one-syndrome path; results are those of
+    the (stubbed) device function on the arguments actually passed."""
+    from qldpc_amd import bp, osd
+    m, n, B = 6, 10, 40
+    calls = []
+
+    class FakeDec:
+        def __init__(self):
+            self.m, self.n = m, n
+
+        def osd0(self, syn, llr, hard):                       # a pure function of its inputs
+            calls.append(len(syn))
+            return ((hard.astype(np.int64) + (llr < 0) + syn.sum(1, keepdims=True)) % 2).astype(np.uint8)
+
+    dec = FakeDec()
+    monkeypatch.setattr(osd, "decoder_for", lambda H: dec)
+    rng = np.random.default_rng(0)
+    syn = rng.integers(0, 2, (B, m)).astype(np.int8)
+    llr = rng.normal(size=(B, n))
+    hard = rng.integers(0, 2, (B, n)).astype(np.int8)
+    conv = rng.random(B) < 0.4
+    monkeypatch.setattr(bp, "_LAST_BATCH", bp._LastBatch(dec, syn, llr, hard, conv))
+
+    def want(i, l=None, h=None):
+        l = llr[i] if l is None else l
+        h = hard[i] if h is None else h
+        return (h.astype(np.int64) + (l < 0) + int(syn[i].sum())) % 2
+
+    fails = np.flatnonzero(~conv)
+    for i in fails[:5]:
+        out = osd.performOSD(None, syn[i].astype(np.int64), llr[i], hard[i].astype(np.int64))
+        assert out.dtype == np.int64 and np.array_equal(out, want(i))
+    assert calls == [len(fails)]                              # one launch for all failing rows
+    i = int(fails[5])
+    assert np.array_equal(osd.performOSD(None, syn[i], llr[i].copy(), hard[i]), want(i))
+    assert calls[-1] == 1 and len(calls) == 2                 # a copy is not a row of the batch
+    llr[i, 3] = -llr[i, 3]                                    # contents changed after the batch call
+    assert np.array_equal(osd.performOSD(None, syn[i], llr[i], hard[i]), want(i))
+    assert len(calls) == 3
+    h2 = 1 - hard[i]
+    assert np.array_equal(osd.performOSD(None, syn[int(fails[6])], llr[int(fails[6])], h2),
+                          want(int(fails[6]), h=h2))
+    assert len(calls) == 4                                    # another hard decision than the batch's
+    j = int(np.flatnonzero(conv)[0])
+    assert np.array_equal(osd.performOSD(None, syn[j], llr[j], hard[j]), want(j))
+    assert len(calls) == 5                                    # converged rows are not precomputed
+    k = int(fails[7])
+    assert np.array_equal(osd.performOSD(None, syn[k], llr[k], hard[k]), want(k)) and len(calls) == 5
+    other = FakeDec()
+    monkeypatch.setattr(osd, "decoder_for", lambda H: other)  # another matrix: never from the cache
+    assert np.array_equal(osd.performOSD(None, syn[k], llr[k], hard[k]), want(k)) and len(calls) == 6
+    monkeypatch.setattr(osd, "decoder_for", lambda H: dec)
+    big = bp._LAST_BATCH_LIMIT // 8 // n + 1                  # LLR arrays above the limit are not kept alive
+    assert bp._LAST_BATCH.llr is llr and big * n * 8 > bp._LAST_BATCH_LIMIT
