@@ -17,7 +17,7 @@ case $S in
   fuzzmc) echo "== fuzz MC 16000"; QBP_FUZZ_CASES=16000 QBP_FUZZ_SEED=99991 timeout -k 10 1100 python -m pytest tests/test_gpu_fuzz.py -q -s -k "monte or mc" > $OUT/fuzz_mc.log 2>&1; echo "fuzz exit=$?"; tail -n 8 $OUT/fuzz_mc.log ;;
   fuzz) echo "== fuzz 3000"; QBP_FUZZ_CASES=3000 QBP_FUZZ_SEED=${FUZZ_SEED:-4242} timeout -k 10 1100 python -m pytest tests/test_gpu_fuzz.py -q -s > $OUT/fuzz.log 2>&1; echo "fuzz exit=$?"; tail -n 8 $OUT/fuzz.log ;;
   rehearsal) echo "== python bench.py --gpus 2 (self-launch; two gloo ranks on this GPU)"
-    timeout -k 10 300 python bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --share-device --batch 20000 --mode forced --no-cpu-baseline > $OUT/bench_2rank_rehearsal.json 2> $OUT/bench_2rank.err; echo "rehearsal exit=$?"; tail -c 700 $OUT/bench_2rank_rehearsal.json; echo ;;
+    timeout -k 10 300 python bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --share-device --batch 20000 --mode forced --no-cpu-baseline > $OUT/bench_2rank_rehearsal.json 2> $OUT/bench_2rank.err; echo "rehearsal exit=$?"; grep "^{\"metric" $OUT/bench_2rank_rehearsal.json > $OUT/tmp.json; mv $OUT/tmp.json $OUT/bench_2rank_rehearsal.json; tail -c 700 $OUT/bench_2rank_rehearsal.json; echo ;;
   config5) echo "== config 5"; timeout -k 10 300 python -m qldpc_amd.mc --code 288 --p 0.1 0.06 0.05 0.04 0.03 0.02 0.01 0.009 0.006 0.005 0.004 0.003 0.002 0.001 --trials 1000000 --osd --out $OUT/config5_288_bposd_1M.json > $OUT/config5.log 2>&1; tail -n 16 $OUT/config5.log ;;
   prof) echo "== rocprof kernel trace of the bench"
     export TMPDIR=/tmp; cd /tmp
