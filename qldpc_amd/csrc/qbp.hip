@@ -627,7 +627,7 @@ try {
         const int W = (n + 31) / 32;
         int NP = 1;
         while (NP < n) NP <<= 1;
-        const size_t lds = (size_t)NP * 12 + (size_t)m * (W + 1) * 4 + (size_t)m * 4 + (size_t)n + 16;
+        const size_t lds = qbp::osd_lds_bytes(m, n, W, NP);
         h->osd_W = W; h->osd_NP = NP; h->osd_lds = (int)((lds + 15) & ~(size_t)15);
         h->osd_ok = lds <= 64 * 1024 && m <= 64 * 32;   // (a lane tracks its rows in a 32-bit mask)
         if (h->osd_ok) {
@@ -1334,7 +1334,7 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_OSD_BIG:
             if (value != 0) { h->osd_ok = false; }
             else {
-                const size_t lds = (size_t)h->osd_NP * 12 + (size_t)h->m * (h->osd_W + 1) * 4 + (size_t)h->m * 4 + (size_t)h->n + 16;
+                const size_t lds = qbp::osd_lds_bytes(h->m, h->n, h->osd_W, h->osd_NP);
                 h->osd_ok = lds <= 64 * 1024 && h->m <= 64 * 32;
                 h->osd_big_ready = false;       // (osd_rank / d_hbits are shared: rebuild on next use)
             }

@@ -55,18 +55,32 @@ __device__ __forceinline__ bool osd_less(unsigned long long ka, int ia, unsigned
     return ka < kb || (ka == kb && ia < ib);
 }
 
-// LDS: double keys[NP]; int idx[NP]; uint32 A[m][W+1]; int pivcol[m]; uint8 sol[n]
-// WW = W + 1 at compile time (0: any width, at most 32 rows per lane).
+// LDS: { u64 keys[NP] | uint32 A[m][W+1] } (the sort is over before the matrix is filled: one region
+// for both -- 8.7 instead of 12.8 KB for [[288,12,18]], 18 instead of 12 resident wavefronts per CU for
+// a kernel that lives on hiding LDS latency); uint16 idx[NP]; int pivcol[m]; uint8 sol[n]
+// (osd_lds_bytes).  WW = W + 1 at compile time (0: any width, at most 32 rows per lane).
+__host__ __device__ inline size_t osd_region0_bytes(int m, int W, int NP)
+{
+    const size_t a = (size_t)NP * 8, b = (size_t)m * (W + 1) * 4;
+    return ((a > b ? a : b) + 7) & ~(size_t)7;
+}
+__host__ __device__ inline size_t osd_lds_bytes(int m, int n, int W, int NP)
+{
+    return osd_region0_bytes(m, W, NP) + (size_t)NP * 2 + (size_t)m * 4 + (size_t)n + 16;
+}
+
 template <int WW>
 __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
 {
     extern __shared__ double osd_smem[];
     const int lane = threadIdx.x;
+    // (row stride W + 1 words.  An odd stride -- 11 for n = 288 -- was measured: no gain, the two halves of a
+    // wavefront are served separately and lanes l, l + 32 are the only ones an even stride maps to one bank)
     const int m = P.m, n = P.n, W = P.W, NP = P.NP, RS = P.W + 1;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(osd_smem);
-    int* idx = reinterpret_cast<int*>(keys + NP);
-    uint32_t* A = reinterpret_cast<uint32_t*>(idx + NP);
-    int* pivcol = reinterpret_cast<int*>(A + (size_t)m * RS);
+    uint32_t* A = reinterpret_cast<uint32_t*>(osd_smem);             // (after the sort: same bytes)
+    uint16_t* idx = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(osd_smem) + osd_region0_bytes(m, W, NP));
+    int* pivcol = reinterpret_cast<int*>(idx + NP);
     uint8_t* sol = reinterpret_cast<uint8_t*>(pivcol + m);
 
     const long long total = P.count_ptr ? *P.count_ptr : P.count;
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
         // ---- 1. ordering = argsort(|llr|)                                    OSD.py:10-11
         for (int i = lane; i < NP; i += 64) {
             keys[i] = i < n ? osd_order_key(llr[i]) : ~0ull;      // padding sorts behind everything
-            idx[i] = i;
+            idx[i] = (uint16_t)i;
         }
         for (int i = lane; i < n; i += 64) sol[i] = hard[i] & 1u;
         __syncthreads();
@@ -92,13 +106,14 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
                     const unsigned long long ka = keys[lo], kb = keys[hi];
                     const int ia = idx[lo], ib = idx[hi];
                     if (osd_less(kb, ib, ka, ia) == up) {
-                        keys[lo] = kb; keys[hi] = ka; idx[lo] = ib; idx[hi] = ia;
+                        keys[lo] = kb; keys[hi] = ka; idx[lo] = (uint16_t)ib; idx[hi] = (uint16_t)ia;
                     }
                 }
                 __syncthreads();
             }
         }
         // ---- 2. A = [H | residual syndrome], residual = syndrome + hard @ H.T  OSD.py:7-8
+        // (A overwrites the sort keys: every lane passed the sort's last barrier)
         for (int r = lane; r < m; r += 64) {
             for (int w = 0; w < W; ++w) A[r * RS + w] = P.hbits[r * W + w];
             unsigned par = syn[r] & 1u;
