@@ -139,7 +139,7 @@ def shader_clock_ghz(device):
     return g2.value if L.ubench_clock_ghz2(device, ctypes.byref(g), ctypes.byref(g2)) == 0 else None
 
 
-def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, num_cu):
+def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, num_cu, iters_per_trip=1):
     """Vector-ALU issue roofline.  needed = issue cycles of the kernel's own instructions: per wave
     and BP iteration, sum over classes of (instructions counted in the machine code of the loaded
     library) x (cycles one SIMD needs per instruction of that class, measured now), times the
@@ -151,7 +151,9 @@ def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, nu
     if len(res) != 1:
         raise RuntimeError(f"{len(res)} kernels match {kernel_symbol!r} in {lib_path}")
     name, mix = next(iter(res.items()))
-    per_class = dict(mix["valu_by_class"])
+    # (the one-barrier forced kernel's loop is unrolled by two: one trip = two BP iterations)
+    per_class = {c: n / iters_per_trip for c, n in mix["valu_by_class"].items()}
+    mix = dict(mix, valu_total=mix["valu_total"] / iters_per_trip)
     if "other_f64" in per_class:                                   # priced like an FMA
         per_class["fma_f64"] = per_class.get("fma_f64", 0) + per_class.pop("other_f64")
     n_total = mix["valu_total"]
@@ -300,6 +302,7 @@ def main():
     geometry = {"threads_per_block": dec.info("threads"), "grid": dec.info("grid"),
                 "lds_bytes": dec.info("lds_bytes")}
     kernel_kind = dec.info("last_kernel")
+    one_bar = int(dec.info("one_barrier"))       # the headline launches ran the one-barrier forced kernel
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
 
     # per-rank kernel times and the reduce on its own
@@ -419,7 +422,7 @@ def main():
 
     if rank == 0:
         dc = 6 if (dec.info("max_row_deg") <= 6 and dec.info("max_col_deg") <= 3) else 8
-        symbol = f"bp_fused_kernelILi{dc}ELi{3 if dc == 6 else 4}ELi0ELb0ELb1E"
+        symbol = f"bp_fused_kernelILi{dc}ELi{3 if dc == 6 else 4}ELi0ELb0ELb1ELi1024ELi1ELb{one_bar}EE"
         S = max(1, geometry["threads_per_block"] // m)
         waves = (geometry["threads_per_block"] + 63) // 64
         wave_iters = B * MAX_ITER / S * waves
@@ -427,7 +430,8 @@ def main():
             if kernel_kind != 1:
                 raise RuntimeError(f"the headline ran kernel kind {kernel_kind}, not the on-chip kernel")
             roof = valu_roofline(_lib.LIB_PATH, symbol, local_rank, wave_iters, kernel_ms * 1e-3,
-                                 dec.info("num_cu"))
+                                 dec.info("num_cu"), iters_per_trip=2 if one_bar else 1)
+            roof["bp_iterations_per_loop_trip"] = 2 if one_bar else 1
             roof["shader_clock_GHz_right_after"] = clock_after_headline
         except Exception as ex:             # a bench line without a roofline is still a bench line
             roof = {"bound": "fp64_valu", "achieved": None, "peak": None, "unit": "Tlane-instr/s",

@@ -202,12 +202,15 @@ enum {
                                           1 global workspace, 2 Q global + half of R in LDS (tests) */
     QBP_OPT_GENERAL_NO_R_SPLIT = 9,    /* 1 = general-H kernel keeps all of R in its global workspace (A/B) */
     QBP_OPT_GENERAL_NO_LDS_TABLES = 8, /* 1 = general-H kernel reads its variable-step tables from L2 (A/B) */
+    QBP_OPT_FORCED_TWO_BARRIERS = 11, /* 1 = QBP_FLAG_FORCE_FULL launches keep both barriers of the iteration
+                                         (default: one barrier, two copies of the messages in LDS; A/B, tests) */
     QBP_OPT_OSD_BIG = 7,         /* 1 = OSD-0 through the workgroup-per-syndrome kernel (matrix in
                                     global memory) even where the one-wavefront kernel fits (tests) */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
     QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 on-chip, 2 general-H, 3 streaming */
     QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109,
-    QBP_INFO_LAST_KERNEL = 110 /* kernel of the last decode launch: 1 on-chip, 2 general-H, 3 streaming */
+    QBP_INFO_LAST_KERNEL = 110, /* kernel of the last decode launch: 1 on-chip, 2 general-H, 3 streaming */
+    QBP_INFO_ONE_BARRIER = 111  /* 1 if the last on-chip launch geometry used the one-barrier forced kernel */
 };
 int qbp_set_option(qbp_handle* h, int32_t option, int64_t value);
 int64_t qbp_get_info(qbp_handle* h, int32_t what);

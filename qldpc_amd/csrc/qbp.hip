@@ -120,6 +120,8 @@ struct qbp_handle {
     DevBuf<double> d_wsQ, d_wsR, d_wsV;
     DevBuf<uint8_t> d_wsC;
     int opt_force_generic = 0;
+    int opt_forced_two_barriers = 0;   // 1: forced-iteration launches keep the second barrier of the iteration (A/B, tests)
+    int last_one_barrier = 0;
     int opt_kernel = 0;             // 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome), 3 streaming
     DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes; general-H Monte-Carlo: syndromes
     DevBuf<uint8_t> d_wsE;           // general-H Monte-Carlo: sampled errors
@@ -170,11 +172,12 @@ using qbp::FusedParams;
 using qbp::LaunchCfg;
 
 // Dynamic LDS of one workgroup of the fused kernel (the carve is documented in qbp_kernels.hpp)
-size_t fused_lds_bytes(int dc, int m, int n, int S)
+size_t fused_lds_bytes(int dc, int m, int n, int S, bool two_copies = false)
 {
     const size_t slot_stride = (size_t)dc * m + 2;
-    size_t lds = ((size_t)S * slot_stride + (size_t)dc * m + 3 * (size_t)S) * 8 +
-                 (5 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
+    size_t lds = (two_copies ? (size_t)qbp::FUSED_R2_OFF_BYTES : 0) +
+                 ((size_t)S * slot_stride + (size_t)dc * m + 3 * (size_t)S) * 8 +
+                 (6 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
                  2 * (size_t)S * (((size_t)n + 3) / 4) * 4;     // err_lds[2][S][n4] (Monte-Carlo builds)
     return (lds + 15) & ~(size_t)15;
 }
@@ -333,7 +336,7 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
     return QBP_OK;
 }
 
-int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
+int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced_decode = false)
 {
     const int m = h->m;
     int S = h->opt_slots;
@@ -349,9 +352,16 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg)
     cfg->dc = h->dc;
     cfg->slot_stride = h->dc * m + 2;
     while (S > 1 && fused_lds_bytes(h->dc, m, h->n, S) > 160 * 1024) --S;   // LDS-limited shapes
+    // forced-iteration decode: the one-barrier kernel when two copies of the messages fit (the first one
+    // below the constant offset of the second) without giving up a slot
+    const bool two = forced_decode && !h->opt_forced_two_barriers && h->dc == DC_SMALL &&
+                     (size_t)S * cfg->slot_stride * 8 <= (size_t)qbp::FUSED_R2_OFF_BYTES &&
+                     fused_lds_bytes(h->dc, m, h->n, S, true) <= 160 * 1024;
+    cfg->one_barrier = two ? 1 : 0;
+    h->last_one_barrier = cfg->one_barrier;
     cfg->S = S;
     cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
-    const size_t lds = fused_lds_bytes(h->dc, m, h->n, S);
+    const size_t lds = fused_lds_bytes(h->dc, m, h->n, S, two);
     if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
     cfg->lds_bytes = (int)lds;
     int per_cu = h->opt_blocks_per_cu;
@@ -783,7 +793,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
         return generic_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr,
                               flags, d_hard, d_converged, d_iters, d_llr, nullptr, 0, 1.0, s);
     LaunchCfg cfg;
-    rc = make_cfg(h, B, &cfg);
+    rc = make_cfg(h, B, &cfg, (flags & QBP_FLAG_FORCE_FULL) != 0);
     if (rc) return rc;
     FusedParams P{};
     fill_static(h, P, cfg);
@@ -1331,6 +1341,8 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_KERNEL:
             if (value < 0 || value > 3) return fail(QBP_E_INVALID, "kernel selector out of range");
             h->opt_kernel = (int)value; return QBP_OK;
+        case QBP_OPT_FORCED_TWO_BARRIERS:
+            h->opt_forced_two_barriers = value != 0; return QBP_OK;
         case QBP_OPT_OSD_BIG:
             if (value != 0) { h->osd_ok = false; }
             else {
@@ -1367,6 +1379,7 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
             if (h->opt_kernel) return h->opt_kernel;
             return h->fused_ok ? 1 : 2;   // (auto picks 3 for small graphs in batches >= 131072)
         case QBP_INFO_LAST_KERNEL: return h->last_kernel;
+        case QBP_INFO_ONE_BARRIER: return h->last_one_barrier;
         case QBP_INFO_THREADS: return h->last_threads;
         case QBP_INFO_LDS_BYTES: return h->last_lds;
         case QBP_INFO_GRID: return h->last_grid;

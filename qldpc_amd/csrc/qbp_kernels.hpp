@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "qbp_math.hpp"
 #include "qbp_mc.hpp"
 
@@ -51,6 +53,12 @@
 #endif
 
 namespace qbp {
+
+// Forced-iteration launches with ONE workgroup barrier per iteration keep two copies of the
+// check->variable messages in LDS; the second copy sits at this constant byte distance from the first
+// (a constant, so that the toggle costs nothing: it lands in the offset field of the ds instructions of a
+// loop unrolled by two).  The first copy, S * slot_stride doubles, must fit below it.
+constexpr int FUSED_R2_OFF_BYTES = 57344;
 
 struct FusedParams {
     // problem
@@ -154,9 +162,20 @@ __device__ __forceinline__ void mc_classify(unsigned long long* mc_lmask, int* m
 //   [S]  MC logical-mask accumulator
 //   then 32-bit words: flag[2][S], mc_weight[S], mc_diff[S], active_count,
 //   mc_count[S][NUM_COUNTERS] (Monte-Carlo mode only), var_lds[DC][m], err_lds[2][S][n4] bytes (MC)
-template <int DC, int DV, int VARIANT, bool MC, bool FORCE_FULL, int MAX_THREADS, int MIN_WAVES_PER_SIMD>
+template <int DC, int DV, int VARIANT, bool MC, bool FORCE_FULL, int MAX_THREADS, int MIN_WAVES_PER_SIMD,
+          bool ONE_BARRIER = false>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kernel(const FusedParams P)
 {
+    // ONE_BAR (forced-iteration decode launches only): one workgroup barrier per iteration instead of two.
+    // The second barrier of an iteration orders (a) the next check step's writes of R after this variable
+    // step's reads and (b) the slot's convergence flag before its readers.  (a) goes away with two copies
+    // of R used alternately; (b) is deferred: whether iteration k satisfied the syndrome is looked at after
+    // the barrier of iteration k + 1 -- the posterior values of iteration k are still in registers then --
+    // which is only affordable when nothing is decided by it but WHEN the outputs are written: in forced
+    // mode every syndrome runs max_iter iterations anyway (and all slots switch syndromes in the same
+    // phase, so the last iteration, which must settle before the registers are reused, keeps its second
+    // barrier for the whole workgroup).  With early exit the next check step would be wasted work.
+    constexpr bool ONE_BAR = ONE_BARRIER && FORCE_FULL && !MC;
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
     const int m = P.m;
@@ -171,20 +190,20 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     const int zoff = DC * m;
     // priors of this check's variables, [edge j][check c], shared by all slots (an LDS read per
     // use instead of 12 VGPRs per lane for the whole kernel)
-    double* const pri_lds = smem + (size_t)S * P.slot_stride;
+    double* const pri_lds = smem + (ONE_BAR ? FUSED_R2_OFF_BYTES / 8 : 0) + (size_t)S * P.slot_stride;
     long long* const next_work = reinterpret_cast<long long*>(pri_lds + DC * m);
     // (the variable indices of the edges, needed only when a syndrome is emitted, sit behind the
     // 32-bit words below: var_lds[DC][m])
     long long* const chunk_ends = next_work + S;     // (LDS, not a register: touched once per syndrome)
     unsigned long long* const mc_lmask = reinterpret_cast<unsigned long long*>(chunk_ends + S);
     int* const words = reinterpret_cast<int*>(mc_lmask + S);
-    int* const flag0 = words;            // [2][S]
-    int* const mc_weight = words + 2 * S;
-    int* const mc_diff = words + 3 * S;
-    int* const work_avg = words + 4 * S;     // [0]: 4 x running mean of the workgroup's iterations per syndrome ([S] reserved)
-    int* const active_count = words + 5 * S;
-    int* const mc_count = words + 5 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
-    int* const var_lds = words + 5 * S + 1 + S * NUM_COUNTERS;     // [DC][m], -1 = padding
+    int* const flag0 = words;            // [3][S] (two in use, three with ONE_BAR)
+    int* const mc_weight = words + 3 * S;
+    int* const mc_diff = words + 4 * S;
+    int* const work_avg = words + 5 * S;     // [0]: 4 x running mean of the workgroup's iterations per syndrome ([S] reserved)
+    int* const active_count = words + 6 * S;
+    int* const mc_count = words + 6 * S + 1 + sl * NUM_COUNTERS;   // this slot's row
+    int* const var_lds = words + 6 * S + 1 + S * NUM_COUNTERS;     // [DC][m], -1 = padding
     // Monte-Carlo mode: sampled error bytes of the slot's trials, [2][S][n4] (n4 = n rounded up to a
     // multiple of 4), written by the slot's first ceil(n/4) lanes one barrier before use.  Two
     // buffers per slot, used alternately by consecutive trials: the emission of a finished trial still
@@ -258,8 +277,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 
     if (leader) {
         Rs[zoff] = 0.0;
+        if constexpr (ONE_BAR) Rs[FUSED_R2_OFF_BYTES / 8 + zoff] = 0.0;
         flag0[slot] = 0;
         flag0[S + slot] = 0;
+        flag0[2 * S + slot] = 0;
         mc_lmask[slot] = 0ull;
         mc_weight[slot] = 0;
         mc_diff[slot] = 0;
@@ -322,7 +343,44 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     bool mc_pending = false;
     int mc_pending_conv = 0, mc_pending_it = 0;
 
-    for (unsigned phase = 0;; ++phase) {
+    double val_keep[DC];          // ONE_BAR: posterior values of the lane's edges, alive until the next phase
+    // decode-mode emission of the values in val[] (one read of the output pointers per emission --
+    // adjacent kernel arguments: a single scalar load -- not one per use)
+    auto emit_decode = [&](const double (&val)[DC], bool conv, int it_out) {
+        const ColdArgs ca = cold_args();
+        double* const o_llr = ca->llr;
+        uint8_t* const o_hard = ca->hard;
+        const long long row = b * ca->n;
+#pragma unroll
+        for (int j = 0; j < DC; ++j) {
+            if ((wmask >> j) & 1u) {
+                const long long o = row + var_lds[j * m + c];
+                if (o_llr) o_llr[o] = val[j];
+                if (o_hard) o_hard[o] = (uint8_t)(val[j] < 0.0);
+            }
+        }
+        const int n_iso = ca->n_iso;
+        for (int i = c; i < n_iso; i += m) {
+            const int v = COLD(iso_vars)[i];
+            const double pv = COLD(prior)[v];
+            if (o_llr) o_llr[row + v] = pv;
+            if (o_hard) o_hard[row + v] = pv < 0.0;
+        }
+        if (c == 0) {
+            if (ca->converged) ca->converged[b] = conv;
+            if (ca->iters) ca->iters[b] = it_out;
+        }
+    };
+    // flag buffers: written in phase p (f_cur), read after the next synchronisation, cleared by the leader
+    // one phase ahead (f_next); ONE_BAR reads them one phase later (f_prev), hence three of them
+    int f_cur = 0, f_next = 1, f_prev = 2;
+    int wg_it = 0;                // ONE_BAR: iteration index of every active slot (they run in step)
+
+    auto phase_body = [&](auto par_tag) -> bool {
+        constexpr int PAR = decltype(par_tag)::value;
+        double* const Rw = ONE_BAR ? Rs + PAR * (FUSED_R2_OFF_BYTES / 8) : Rs;     // this phase's copy of R
+        double val_phase[DC];     // (two-barrier builds: the values do not outlive the phase)
+        double (&val)[DC] = ONE_BAR ? val_keep : val_phase;
         if constexpr (MC) {
             // Sample the errors of a trial that starts in this phase: one Philox evaluation per
             // four qubits, by the first ceil(n/4) lanes of the slot; the extra barrier (Monte-Carlo
@@ -368,7 +426,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     const double s = Q[j] < 0.0 ? -1.0 : 1.0;
                     const double mag = (__builtin_fabs(Q[j]) == min1) ? min2 : min1;
                     const double r = (as * (sprod * s)) * mag;
-                    Rs[j * m + c] = r;
+                    Rw[j * m + c] = r;
                     if constexpr (HOLD_R) R[j] = r;
                 }
             } else {
@@ -389,16 +447,23 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                                           __double2loint(po));   // * syndrome_sign
                     double r = atanh2(clip_unit<VARIANT>(po));
                     if (VARIANT == 1) r = r * P.alpha;
-                    Rs[j * m + c] = r;
+                    Rw[j * m + c] = r;
                     if constexpr (HOLD_R) R[j] = r;
                 }
             }
         }
         __syncthreads();                                          // B1
-        if (*active_count == 0) break;
+        if (*active_count == 0) return true;
 
         // ================= variable step (per edge of this check) ============================
-        double val[DC];
+        if constexpr (ONE_BAR) {
+            // iteration it - 1 of this syndrome satisfied it (its flag is complete since the barrier above):
+            // its posterior values, still in val[], are the outputs (beliefPropagationGPU.py:160-167)
+            if (active && it > 0 && !frozen && flag0[f_prev * S + slot] == 0) {
+                emit_decode(val, true, it - 1);
+                frozen = true;
+            }
+        }
         if (active) {
             bool odd = sbit != 0;                                 // parity of the row vs syndrome
             // Issue the LDS gathers of a group of edges before the first add (one lgkmcnt wait per
@@ -421,13 +486,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                                 unsigned pk = nbr[j0 + jj][k / 2];
                                 asm volatile("" : "+v"(pk));
                                 o = (k & 1) ? pk >> 16 : pk & 0xffffu;
-                                rr[jj][k] = Rs[o];
+                                rr[jj][k] = Rw[o];
                             } else {
-                                rr[jj][k] = Rs[nbr[j0 + jj][k]];
+                                rr[jj][k] = Rw[nbr[j0 + jj][k]];
                             }
                         }
                     if constexpr (!HOLD_R)
-                        if (j0 + jj < DC) rown[jj] = Rs[(j0 + jj) * m + c];
+                        if (j0 + jj < DC) rown[jj] = Rw[(j0 + jj) * m + c];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -455,10 +520,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 for (int j = 0; j < DC; ++j)
                     if (!((vmask >> j) & 1u)) Q[j] = __builtin_inf();   // padding stays neutral
             }
-            if (odd) flag0[(phase & 1u) * S + slot] = 1;          // this check is unsatisfied
+            if (odd) flag0[f_cur * S + slot] = 1;                 // this check is unsatisfied
         }
         if (leader) {
-            flag0[((phase + 1u) & 1u) * S + slot] = 0;
+            flag0[f_next * S + slot] = 0;
             if (refill) {
                 long long nx = next_work[slot] + 1;
                 if (nx == chunk_ends[slot]) {
@@ -479,12 +544,16 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 }
             }
         }
-        __syncthreads();                                          // B2
+        // (ONE_BAR: only the last iteration of a syndrome settles here; wg_it is workgroup-uniform)
+        const bool settle = !ONE_BAR || wg_it == max_iter - 1;
+        if (settle) __syncthreads();                              // B2
 
         // ================= convergence / output / next syndrome ==============================
-        if (active) {
-            const bool conv = flag0[(phase & 1u) * S + slot] == 0;
-            const bool last = it == max_iter - 1;
+        if (active && settle) {
+            const bool conv = flag0[f_cur * S + slot] == 0;
+            // (ONE_BAR: this block runs once per syndrome; reading the limit from the kernel-argument
+            // segment here is also what tells tools/valu_mix.py so -- its rule for once-per-syndrome code)
+            const bool last = it == (ONE_BAR ? COLD(max_iter) : max_iter) - 1;
             if (!frozen && (conv || last)) {
                 if constexpr (MC) {
                     const ColdArgs ca = cold_args();     // one read of the cold arguments per emission
@@ -548,31 +617,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     }
                     if (c == 0) { mc_pending = true; mc_pending_conv = conv; mc_pending_it = it; }
                 } else {
-                    // one read of the output pointers per emission (adjacent kernel arguments: a
-                    // single scalar load), not one per use
-                    const ColdArgs ca = cold_args();
-                    double* const o_llr = ca->llr;
-                    uint8_t* const o_hard = ca->hard;
-                    const long long row = b * ca->n;
-#pragma unroll
-                    for (int j = 0; j < DC; ++j) {
-                        if ((wmask >> j) & 1u) {
-                            const long long o = row + var_lds[j * m + c];
-                            if (o_llr) o_llr[o] = val[j];
-                            if (o_hard) o_hard[o] = (uint8_t)(val[j] < 0.0);
-                        }
-                    }
-                    const int n_iso = ca->n_iso;
-                    for (int i = c; i < n_iso; i += m) {
-                        const int v = COLD(iso_vars)[i];
-                        const double pv = COLD(prior)[v];
-                        if (o_llr) o_llr[row + v] = pv;
-                        if (o_hard) o_hard[row + v] = pv < 0.0;
-                    }
-                    if (c == 0) {
-                        if (ca->converged) ca->converged[b] = conv;
-                        if (ca->iters) ca->iters[b] = it;
-                    }
+                    emit_decode(val, conv, it);
                 }
             }
             if (conv) frozen = true;
@@ -599,6 +644,19 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             } else {
                 ++it;
             }
+        } else if (active) {
+            ++it;                                                 // (ONE_BAR, not the last iteration)
+        }
+        {   // next phase
+            const int t = f_prev; f_prev = f_cur; f_cur = f_next; f_next = ONE_BAR ? t : f_prev;
+            if constexpr (ONE_BAR) wg_it = wg_it == max_iter - 1 ? 0 : wg_it + 1;
+        }
+        return false;
+    };
+    for (;;) {
+        if (phase_body(std::integral_constant<int, 0>{})) break;
+        if constexpr (ONE_BAR) {
+            if (phase_body(std::integral_constant<int, 1>{})) break;
         }
     }
 

@@ -1,4 +1,4 @@
-// libqbp.so, translation unit of the on-chip kernel (qbp_kernels.hpp): its 24 instantiations.
+// libqbp.so, translation unit of the on-chip kernel (qbp_kernels.hpp): its 27 instantiations.
 #define QBP_DEFINE_KERNELS 1
 #include <hip/hip_runtime.h>
 
@@ -9,10 +9,10 @@
 namespace qbp {
 namespace {
 
-template <int DC, int DV, int VARIANT, bool MC, bool FORCE, int MAXT, int MINW>
+template <int DC, int DV, int VARIANT, bool MC, bool FORCE, int MAXT, int MINW, bool ONEBAR = false>
 hipError_t launch_k(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
 {
-    auto kern = bp_fused_kernel<DC, DV, VARIANT, MC, FORCE, MAXT, MINW>;
+    auto kern = bp_fused_kernel<DC, DV, VARIANT, MC, FORCE, MAXT, MINW, ONEBAR>;
     // the dynamic-LDS limit of an instantiation is raised once per device and size (the attribute
     // call costs a few microseconds, which matters for one-syndrome-per-call users)
     static thread_local int lds_set[64] = {0};
@@ -32,6 +32,10 @@ template <int VARIANT, bool MC, int MAXT, int MINW = 1>
 hipError_t launch_one(const FusedParams& P, const LaunchCfg& cfg, hipStream_t stream)
 {
     const bool force = (P.flags & QBP_FLAG_FORCE_FULL) != 0;
+    if constexpr (!MC) {      // (the wide shape is 1.5 % slower with one barrier -- more spills -- and keeps two)
+        if (force && cfg.one_barrier && cfg.dc == DC_SMALL)
+            return launch_k<DC_SMALL, DV_SMALL, VARIANT, false, true, MAXT, MINW, true>(P, cfg, stream);
+    }
     if (cfg.dc == DC_SMALL)
         return force ? launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, true, MAXT, MINW>(P, cfg, stream)
                      : launch_k<DC_SMALL, DV_SMALL, VARIANT, MC, false, MAXT, MINW>(P, cfg, stream);

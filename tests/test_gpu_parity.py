@@ -79,6 +79,39 @@ def test_force_full_same_outputs_and_determinism():
         assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
+@pytest.mark.parametrize("name", ["[[72, 12, 6]]", "[[144, 12, 12]]", "[[288, 12, 18]]", "steane"])
+def test_forced_mode_one_barrier_kernel_equals_two_barrier_kernel_and_early_exit(name):
+    """QBP_FLAG_FORCE_FULL launches of the (6, 3) shape run the kernel with ONE workgroup barrier per iteration
+    (two copies of the messages in LDS, the convergence test of iteration k read one phase later:
+    qbp_kernels.hpp, ONE_BAR).  Its outputs must equal, bit for bit, those of the two-barrier forced kernel
+    (QBP_OPT_FORCED_TWO_BARRIERS) and of the early-exit kernel -- all three variants of the update, several
+    iteration limits (1 and 2: the last iteration of a syndrome is also its first / second), batches larger
+    than the resident slots (work fetch) and smaller (idle slots)."""
+    code = codes.load_code(name)
+    H = code.Hx
+    dec = bp.decoder_for(H)
+    rng = np.random.default_rng(11)
+    for p, B in ((0.02, 300), (0.07, 9000)):
+        syn = ((rng.random((B, code.n)) < p).astype(np.int64) @ H.T % 2).astype(np.uint8)
+        prior = np.full(code.n, np.log((1 - p) / p)) * rng.uniform(0.8, 1.2, code.n)
+        for variant, kw in ((0, {}), (1, dict(alpha=0.9, damping=0.8, clip_llr=20.0)),
+                            (2, dict(alpha=0.8, damping=0.7, clip_llr=25.0))):
+            for max_iter in (1, 2, 3, 17, 50):
+                early = dec.decode(syn, prior, max_iter, variant, **kw)
+                one = dec.decode(syn, prior, max_iter, variant, flags=_lib.FLAG_FORCE_FULL, **kw)
+                used_one = dec.info("one_barrier")
+                dec.set_option(_lib.OPT_FORCED_TWO_BARRIERS, 1)
+                try:
+                    two = dec.decode(syn, prior, max_iter, variant, flags=_lib.FLAG_FORCE_FULL, **kw)
+                    assert dec.info("one_barrier") == 0
+                finally:
+                    dec.set_option(_lib.OPT_FORCED_TWO_BARRIERS, 0)
+                assert used_one == 1, (name, "the one-barrier kernel should fit this shape")
+                for x, y, z in zip(early, one, two):
+                    assert np.array_equal(x, y, equal_nan=True) and np.array_equal(x, z, equal_nan=True), \
+                        (name, p, variant, max_iter)
+
+
 def test_min_sum_and_damped_vs_oracle():
     code = codes.load_code("[[144, 12, 12]]")       # BASELINE config 3 parameterisation
     rng = np.random.default_rng(4)
