@@ -13,6 +13,8 @@
 //      np.sum(R, axis=0) accumulates in), value_j = sum + prior_j, Q_j = value_j - R_j, hard
 //      bit, parity of the row vs the syndrome bit -> per-slot "unsatisfied" flag (:129-139)
 //   4. barrier, read the flag: converged / iteration limit -> emit outputs, fetch next syndrome.
+//      (QBP_FLAG_FORCE_FULL launches of the (6, 3) shape skip this barrier: two copies of R, the flag
+//      read one phase later -- see ONE_BAR in the kernel.)
 // No message ever touches HBM: per syndrome the kernel reads m syndrome bytes and writes
 // n hard bytes + n LLR doubles + 5 bytes.  Slots fetch work from a global atomic counter, so a
 // slot whose syndrome converges early (reference semantics: return at the first syndrome match)
