@@ -122,6 +122,7 @@ struct qbp_handle {
     int opt_force_generic = 0;
     int opt_forced_two_barriers = 0;   // 1: forced-iteration launches keep the second barrier of the iteration (A/B, tests)
     int last_one_barrier = 0;
+    int opt_no_r0_table = 0;           // 1: early-exit launches compute the first check step like every other (A/B, tests)
     int opt_kernel = 0;             // 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome), 3 streaming
     DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes; general-H Monte-Carlo: syndromes
     DevBuf<uint8_t> d_wsE;           // general-H Monte-Carlo: sampled errors
@@ -172,10 +173,10 @@ using qbp::FusedParams;
 using qbp::LaunchCfg;
 
 // Dynamic LDS of one workgroup of the fused kernel (the carve is documented in qbp_kernels.hpp)
-size_t fused_lds_bytes(int dc, int m, int n, int S, bool two_copies = false)
+size_t fused_lds_bytes(int dc, int m, int n, int S, bool two_copies = false, bool r0_table = false)
 {
     const size_t slot_stride = (size_t)dc * m + 2;
-    size_t lds = (two_copies ? (size_t)qbp::FUSED_R2_OFF_BYTES : 0) +
+    size_t lds = (two_copies ? (size_t)qbp::FUSED_R2_OFF_BYTES : 0) + (r0_table ? (size_t)2 * dc * m * 8 : 0) +
                  ((size_t)S * slot_stride + (size_t)dc * m + 3 * (size_t)S) * 8 +
                  (6 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
                  2 * (size_t)S * (((size_t)n + 3) / 4) * 4;     // err_lds[2][S][n4] (Monte-Carlo builds)
@@ -336,7 +337,7 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
     return QBP_OK;
 }
 
-int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced_decode = false)
+int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced = false, bool mc = false)
 {
     const int m = h->m;
     int S = h->opt_slots;
@@ -354,14 +355,17 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced_decode = fa
     while (S > 1 && fused_lds_bytes(h->dc, m, h->n, S) > 160 * 1024) --S;   // LDS-limited shapes
     // forced-iteration decode: the one-barrier kernel when two copies of the messages fit (the first one
     // below the constant offset of the second) without giving up a slot
-    const bool two = forced_decode && !h->opt_forced_two_barriers && h->dc == DC_SMALL &&
+    const bool two = forced && !mc && !h->opt_forced_two_barriers && h->dc == DC_SMALL &&
                      (size_t)S * cfg->slot_stride * 8 <= (size_t)qbp::FUSED_R2_OFF_BYTES &&
                      fused_lds_bytes(h->dc, m, h->n, S, true) <= 160 * 1024;
     cfg->one_barrier = two ? 1 : 0;
     h->last_one_barrier = cfg->one_barrier;
     cfg->S = S;
     cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
-    const size_t lds = fused_lds_bytes(h->dc, m, h->n, S, two);
+    // early exit: the first check step's messages as an LDS table, when it fits beside S slots
+    const bool r0 = !forced && !h->opt_no_r0_table && fused_lds_bytes(h->dc, m, h->n, S, false, true) <= 160 * 1024;
+    cfg->r0_table = r0 ? 1 : 0;
+    const size_t lds = fused_lds_bytes(h->dc, m, h->n, S, two, r0);
     if (lds > 160 * 1024) return fail(QBP_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
     cfg->lds_bytes = (int)lds;
     int per_cu = h->opt_blocks_per_cu;
@@ -400,6 +404,7 @@ void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg)
 {
     P.m = h->m; P.n = h->n;
     P.S = cfg.S; P.slot_stride = cfg.slot_stride;
+    P.r0_table = cfg.r0_table;
     P.padded = h->padded ? 1 : 0;
     P.n_words4 = (h->n + 3) / 4;
     P.tab_var = h->d_tab_var.p; P.tab_nbr = h->d_tab_nbr.p; P.tab_writer = h->d_tab_writer.p;
@@ -793,7 +798,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
         return generic_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr,
                               flags, d_hard, d_converged, d_iters, d_llr, nullptr, 0, 1.0, s);
     LaunchCfg cfg;
-    rc = make_cfg(h, B, &cfg, (flags & QBP_FLAG_FORCE_FULL) != 0);
+    rc = make_cfg(h, B, &cfg, (flags & QBP_FLAG_FORCE_FULL) != 0, false);
     if (rc) return rc;
     FusedParams P{};
     fill_static(h, P, cfg);
@@ -1236,7 +1241,7 @@ try {
         return osd ? osd_pass() : QBP_OK;
     }
     LaunchCfg cfg;
-    rc = make_cfg(h, T, &cfg);
+    rc = make_cfg(h, T, &cfg, (flags & QBP_FLAG_FORCE_FULL) != 0, true);
     if (rc) return rc;
     FusedParams P{};
     fill_static(h, P, cfg);
@@ -1309,7 +1314,7 @@ try {
     }
     HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, qbp::NUM_COUNTERS * sizeof(long long), s));
     LaunchCfg cfg;
-    rc = make_cfg(h, T, &cfg);
+    rc = make_cfg(h, T, &cfg, false, true);
     if (rc) return rc;
     FusedParams P{};
     fill_static(h, P, cfg);
@@ -1341,6 +1346,8 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_KERNEL:
             if (value < 0 || value > 3) return fail(QBP_E_INVALID, "kernel selector out of range");
             h->opt_kernel = (int)value; return QBP_OK;
+        case QBP_OPT_NO_FIRST_STEP_TABLE:
+            h->opt_no_r0_table = value != 0; return QBP_OK;
         case QBP_OPT_FORCED_TWO_BARRIERS:
             h->opt_forced_two_barriers = value != 0; return QBP_OK;
         case QBP_OPT_OSD_BIG:

@@ -74,6 +74,7 @@ struct FusedParams {
     unsigned flags;
     int padded;                 // some row has fewer than DC edges (irregular H)
     int n_words4;               // ceil(n / 4)
+    int r0_table;               // LDS holds the first check step's messages (early-exit launches, when it fits)
     double alpha, damping, clip_llr;
     // outputs (decode mode; may be null)
     uint8_t* hard;
@@ -193,7 +194,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // priors of this check's variables, [edge j][check c], shared by all slots (an LDS read per
     // use instead of 12 VGPRs per lane for the whole kernel)
     double* const pri_lds = smem + (ONE_BAR ? FUSED_R2_OFF_BYTES / 8 : 0) + (size_t)S * P.slot_stride;
-    long long* const next_work = reinterpret_cast<long long*>(pri_lds + DC * m);
+    // Early-exit launches: the check->variable messages of a syndrome's FIRST check step, which depend
+    // on nothing but the priors and the check's syndrome bit -- r0_lds[bit][edge j][check c], computed once
+    // per workgroup by the kernel's own check-step code (same bits).  At low error rates most syndromes
+    // need one or two iterations, and the first check step is most of the first one.
+    const bool use_r0 = !FORCE_FULL && P.r0_table != 0;
+    double* const r0_lds = pri_lds + DC * m;
+    long long* const next_work = reinterpret_cast<long long*>(r0_lds + (use_r0 ? 2 * DC * m : 0));
     // (the variable indices of the edges, needed only when a syndrome is emitted, sit behind the
     // 32-bit words below: var_lds[DC][m])
     long long* const chunk_ends = next_work + S;     // (LDS, not a register: touched once per syndrome)
@@ -217,6 +224,60 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     auto err_buf = [&]() -> unsigned char* {
         const int n4 = COLD(n_words4) * 4;
         return reinterpret_cast<unsigned char*>(var_lds + DC * m) + (size_t)(sl + (err_par ? S : 0)) * n4;
+    };
+
+    // ---- check step of one row: q[DC] -> put(j, r) for its DC edges --------------------------------
+    auto check_step = [&](const double (&q)[DC], unsigned sb, auto&& put) {
+        if constexpr (VARIANT == 2) {
+            // rework/decoding.py:28-56
+            double sprod = 1.0, min1 = __builtin_inf();
+            int min1_j = 0;
+            bool anynan = false;
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const double s = q[j] < 0.0 ? -1.0 : 1.0;   // sign, 0 -> +1, padding +1
+                sprod *= s;
+                anynan |= q[j] != q[j];
+                const double a = __builtin_fabs(q[j]);
+                if (a < min1) { min1 = a; min1_j = j; }       // first occurrence
+            }
+            // np.sign(nan) = nan: one NaN message (inf - inf with infinite priors) makes the
+            // row's sign product, hence every R of the row, NaN
+            if (anynan) sprod = __builtin_nan("");
+            double min2 = __builtin_inf();
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const double a = __builtin_fabs(q[j]);
+                if (j != min1_j && a < min2) min2 = a;
+            }
+            const double as = sb ? -P.alpha : P.alpha;        // alpha * syndrome_sign
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const double s = q[j] < 0.0 ? -1.0 : 1.0;
+                const double mag = (__builtin_fabs(q[j]) == min1) ? min2 : min1;
+                put(j, (as * (sprod * s)) * mag);
+            }
+        } else {
+            double t[DC];
+            double prod;
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                t[j] = tanh_half_msg<VARIANT>(q[j]);
+                prod = (j == 0) ? t[0] : prod * t[j];         // np.prod, ascending column
+            }
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+                // prod / ts, correctly rounded like numpy's division: |prod| <= 1 and
+                // 1e-15 <= |ts| <= 1, so no operand scaling is needed (div_nr's precondition)
+                double po = div_nr(prod, ts);
+                po = __hiloint2double(__double2hiint(po) ^ (int)(sb << 31),
+                                      __double2loint(po));   // * syndrome_sign
+                double r = atanh2(clip_unit<VARIANT>(po));
+                if (VARIANT == 1) r = r * P.alpha;
+                put(j, r);
+            }
+        }
     };
 
     // ---- per-lane static tables (registers for the whole kernel) ---------------------------
@@ -248,6 +309,14 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         }
     }
     if (lane_valid) wmask = P.tab_writer[c];
+    if (use_r0 && lane_valid && slot == 0) {
+        // (this lane wrote the priors it reads here; the table is published by the barrier before the loop)
+        double qp[DC];
+#pragma unroll
+        for (int j = 0; j < DC; ++j) qp[j] = pri_lds[j * m + c];
+        check_step(qp, 0u, [&](int j, double r) { r0_lds[j * m + c] = r; });
+        check_step(qp, 1u, [&](int j, double r) { r0_lds[(DC + j) * m + c] = r; });
+    }
 
     const long long B = P.B;
     const long long total_slots = (long long)gridDim.x * S;
@@ -400,58 +469,20 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         if (need_start) { start_syndrome(); need_start = false; }
         // ================= check step =======================================================
         if (active) {
-            if constexpr (VARIANT == 2) {
-                // rework/decoding.py:28-56
-                double sprod = 1.0, min1 = __builtin_inf();
-                int min1_j = 0;
-                bool anynan = false;
+            if (use_r0 && it == 0) {
+                // first check step of a syndrome: from the workgroup's table (see r0_lds)
+                const double* const r0 = r0_lds + (sbit ? DC * m : 0);
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
-                    const double s = Q[j] < 0.0 ? -1.0 : 1.0;   // sign, 0 -> +1, padding +1
-                    sprod *= s;
-                    anynan |= Q[j] != Q[j];
-                    const double a = __builtin_fabs(Q[j]);
-                    if (a < min1) { min1 = a; min1_j = j; }       // first occurrence
-                }
-                // np.sign(nan) = nan: one NaN message (inf - inf with infinite priors) makes the
-                // row's sign product, hence every R of the row, NaN
-                if (anynan) sprod = __builtin_nan("");
-                double min2 = __builtin_inf();
-#pragma unroll
-                for (int j = 0; j < DC; ++j) {
-                    const double a = __builtin_fabs(Q[j]);
-                    if (j != min1_j && a < min2) min2 = a;
-                }
-                const double as = sbit ? -P.alpha : P.alpha;      // alpha * syndrome_sign
-#pragma unroll
-                for (int j = 0; j < DC; ++j) {
-                    const double s = Q[j] < 0.0 ? -1.0 : 1.0;
-                    const double mag = (__builtin_fabs(Q[j]) == min1) ? min2 : min1;
-                    const double r = (as * (sprod * s)) * mag;
+                    const double r = r0[j * m + c];
                     Rw[j * m + c] = r;
                     if constexpr (HOLD_R) R[j] = r;
                 }
             } else {
-                double t[DC];
-                double prod;
-#pragma unroll
-                for (int j = 0; j < DC; ++j) {
-                    t[j] = tanh_half_msg<VARIANT>(Q[j]);
-                    prod = (j == 0) ? t[0] : prod * t[j];         // np.prod, ascending column
-                }
-#pragma unroll
-                for (int j = 0; j < DC; ++j) {
-                    const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
-                    // prod / ts, correctly rounded like numpy's division: |prod| <= 1 and
-                    // 1e-15 <= |ts| <= 1, so no operand scaling is needed (div_nr's precondition)
-                    double po = div_nr(prod, ts);
-                    po = __hiloint2double(__double2hiint(po) ^ (int)(sbit << 31),
-                                          __double2loint(po));   // * syndrome_sign
-                    double r = atanh2(clip_unit<VARIANT>(po));
-                    if (VARIANT == 1) r = r * P.alpha;
+                check_step(Q, sbit, [&](int j, double r) {
                     Rw[j * m + c] = r;
                     if constexpr (HOLD_R) R[j] = r;
-                }
+                });
             }
         }
         __syncthreads();                                          // B1

@@ -25,6 +25,7 @@ constexpr int DC_WIDE = 8, DV_WIDE = 4;
 struct LaunchCfg {
     int S, threads, lds_bytes, grid, slot_stride, dc;
     int one_barrier;        // forced-iteration decode launch with two copies of R in LDS (qbp_kernels.hpp)
+    int r0_table;           // early-exit launch with the first check step's messages tabulated in LDS
 };
 
 // qbp_tu_fused.hip

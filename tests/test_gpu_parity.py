@@ -112,6 +112,50 @@ def test_forced_mode_one_barrier_kernel_equals_two_barrier_kernel_and_early_exit
                         (name, p, variant, max_iter)
 
 
+@pytest.mark.parametrize("name", ["[[72, 12, 6]]", "[[288, 12, 18]]", "steane", "irregular"])
+def test_first_check_step_table_changes_nothing(name):
+    """Early-exit launches take a syndrome's first check step from a per-workgroup LDS table (its messages
+    depend on the priors and the syndrome bit only: qbp_kernels.hpp, r0_lds).  Outputs with the table
+    must equal those without (QBP_OPT_NO_FIRST_STEP_TABLE), bit for bit: three variants, non-uniform and
+    extreme priors (0, negative, +-inf), an irregular matrix with padded rows, decode and Monte-Carlo."""
+    rng = np.random.default_rng(5)
+    if name == "irregular":
+        H = (rng.random((40, 90)) < 0.05).astype(np.int64)
+        H[:, 0] = 0
+        H[3] = 0
+        H[3, :2] = 1                         # a weight-2 check, an isolated variable
+        H = H[(H.sum(1) <= 6)]
+        H = H[:, H.sum(0) <= 3]
+        Lx, dist = (rng.random((3, H.shape[1])) < 0.3).astype(np.uint8), 4
+    else:
+        code = codes.load_code(name)
+        H = code.Hx
+        Lx, dist = (code.Lx, code.distance) if code.Lx is not None else ((rng.random((2, H.shape[1])) < 0.3).astype(np.uint8), 3)
+    n = H.shape[1]
+    dec = bp.decoder_for(H)
+    assert dec.info("kernel_kind") == 1
+    p = 0.04
+    syn = ((rng.random((5000, n)) < p).astype(np.int64) @ H.T % 2).astype(np.uint8)
+    priors = [np.full(n, np.log((1 - p) / p)),
+              np.log((1 - p) / p) * rng.uniform(0.2, 2.0, n),
+              np.where(rng.random(n) < 0.1, rng.choice([0.0, -1.5, np.inf, -np.inf], n), 3.0)]
+    for prior in priors:
+        for variant, kw in ((0, {}), (1, dict(alpha=0.9, damping=0.8, clip_llr=20.0)),
+                            (2, dict(alpha=0.8, damping=0.7, clip_llr=25.0))):
+            for max_iter in (1, 4, 30):
+                with_table = dec.decode(syn, prior, max_iter, variant, **kw)
+                mc_a = dec.mc_run(Lx, dist, p, prior, 0, 20000, seed=9, max_iter=max_iter, variant=variant, **kw)
+                dec.set_option(_lib.OPT_NO_FIRST_STEP_TABLE, 1)
+                try:
+                    without = dec.decode(syn, prior, max_iter, variant, **kw)
+                    mc_b = dec.mc_run(Lx, dist, p, prior, 0, 20000, seed=9, max_iter=max_iter, variant=variant, **kw)
+                finally:
+                    dec.set_option(_lib.OPT_NO_FIRST_STEP_TABLE, 0)
+                for x, y in zip(with_table, without):
+                    assert np.array_equal(x, y, equal_nan=True), (name, variant, max_iter)
+                assert np.array_equal(mc_a, mc_b), (name, variant, max_iter)
+
+
 def test_min_sum_and_damped_vs_oracle():
     code = codes.load_code("[[144, 12, 12]]")       # BASELINE config 3 parameterisation
     rng = np.random.default_rng(4)
