@@ -202,6 +202,8 @@ enum {
                                           1 global workspace, 2 Q global + half of R in LDS (tests) */
     QBP_OPT_GENERAL_NO_R_SPLIT = 9,    /* 1 = general-H kernel keeps all of R in its global workspace (A/B) */
     QBP_OPT_GENERAL_NO_LDS_TABLES = 8, /* 1 = general-H kernel reads its variable-step tables from L2 (A/B) */
+    QBP_OPT_EARLY_EXIT_FULL_WG = 13,  /* 1 = early-exit launches use workgroups of 16 wavefronts like forced ones
+                                         (default: two of 8 per CU; A/B) */
     QBP_OPT_NO_FIRST_STEP_TABLE = 12, /* 1 = early-exit launches of the on-chip kernel compute a syndrome's first
                                          check step like every other (default: from a per-workgroup LDS table of
                                          its messages, which depend on the priors and the syndrome bit only; A/B, tests) */

@@ -29,6 +29,7 @@ COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "in
 OPT_SLOTS_PER_BLOCK, OPT_BLOCKS_PER_CU, OPT_FORCE_GENERIC, OPT_KERNEL, OPT_GENERAL_THREADS, OPT_OSD_BIG, OPT_GENERAL_NO_LDS_TABLES, OPT_GENERAL_NO_R_SPLIT, OPT_GENERAL_MEM = 1, 2, 4, 5, 6, 7, 8, 9, 10
 OPT_FORCED_TWO_BARRIERS = 11
 OPT_NO_FIRST_STEP_TABLE = 12
+OPT_EARLY_EXIT_FULL_WG = 13
 KERNEL_AUTO, KERNEL_ON_CHIP, KERNEL_GENERAL, KERNEL_STREAM = 0, 1, 2, 3
 INFO = dict(m=100, n=101, edges=102, max_row_deg=103, max_col_deg=104, kernel_kind=105,
             threads=106, lds_bytes=107, grid=108, num_cu=109, last_kernel=110, one_barrier=111)

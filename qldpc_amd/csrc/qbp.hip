@@ -122,6 +122,7 @@ struct qbp_handle {
     int opt_force_generic = 0;
     int opt_forced_two_barriers = 0;   // 1: forced-iteration launches keep the second barrier of the iteration (A/B, tests)
     int last_one_barrier = 0;
+    int opt_early_exit_full_wg = 0;    // 1: early-exit launches use 16-wavefront workgroups like forced ones (A/B)
     int opt_no_r0_table = 0;           // 1: early-exit launches compute the first check step like every other (A/B, tests)
     int opt_kernel = 0;             // 0 auto, 1 on-chip, 2 general-H (workgroup per syndrome), 3 streaming
     DevBuf<uint8_t> d_wsS;           // streaming kernel: transposed syndromes; general-H Monte-Carlo: syndromes
@@ -345,6 +346,15 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced = false, bo
         // 16 wavefronts per workgroup (4 per SIMD at the kernel's 128-VGPR budget) was the fastest
         // geometry measured (profiles/r01_tune.txt); small batches spread over the CUs instead.
         S = std::max(1, 1024 / std::max(m, 1));
+        // With early exit the slots of a workgroup are in different iterations, yet every one of them
+        // waits at the workgroup's barriers for the slowest (a slot in its first iteration copies six
+        // table entries, its neighbour evaluates six tanh / division / atanh chains): two workgroups
+        // of 8 wavefronts per CU -- half the slots behind each barrier, and one workgroup computing
+        // while the other synchronises or writes results -- are 2 - 18 % faster on every early-exit
+        // workload measured, although [[288,12,18]] then runs 6 syndromes per CU instead of 7
+        // (profiles/r02_ab_work_chunk.txt, second part).  Not for the (8, 4) shape (m > 512).
+        if (!forced && !h->opt_early_exit_full_wg && 512 / std::max(m, 1) >= 1 && S >= 2)
+            S = 512 / m;
         const long long spread = (B + h->num_cu - 1) / std::max(h->num_cu, 1);
         if (spread < S) S = (int)std::max<long long>(spread, 1);
     }
@@ -374,7 +384,8 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced = false, bo
         // two workgroups per CU are queued: with early exit the second round evens out the tail
         // (measured +10 % at p = 0.01, neutral when every syndrome runs max_iter iterations).
         const int waves = cfg->threads / 64;
-        per_cu = std::max(2, std::min(16 / std::max(waves, 1), (int)(160 * 1024 / lds)));
+        const int resident = std::max(1, std::min(16 / std::max(waves, 1), (int)(160 * 1024 / lds)));
+        per_cu = 2 * resident;
     }
     const long long want = (B + S - 1) / S;
     cfg->grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cu * per_cu));
@@ -1346,6 +1357,8 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         case QBP_OPT_KERNEL:
             if (value < 0 || value > 3) return fail(QBP_E_INVALID, "kernel selector out of range");
             h->opt_kernel = (int)value; return QBP_OK;
+        case QBP_OPT_EARLY_EXIT_FULL_WG:
+            h->opt_early_exit_full_wg = value != 0; return QBP_OK;
         case QBP_OPT_NO_FIRST_STEP_TABLE:
             h->opt_no_r0_table = value != 0; return QBP_OK;
         case QBP_OPT_FORCED_TWO_BARRIERS:
