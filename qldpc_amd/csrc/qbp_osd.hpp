@@ -76,7 +76,9 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
     const int lane = threadIdx.x;
     // (row stride W + 1 words.  An odd stride -- 11 for n = 288 -- was measured: no gain, the two halves of a
     // wavefront are served separately and lanes l, l + 32 are the only ones an even stride maps to one bank)
-    const int m = P.m, n = P.n, W = P.W, NP = P.NP, RS = P.W + 1;
+    // (the row stride as a compile-time constant where the instantiation knows it: the ten accesses of a
+    // row become wide LDS instructions)
+    const int m = P.m, n = P.n, W = WW > 0 ? WW - 1 : P.W, NP = P.NP, RS = W + 1;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(osd_smem);
     uint32_t* A = reinterpret_cast<uint32_t*>(osd_smem);             // (after the sort: same bytes)
     uint16_t* idx = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(osd_smem) + osd_region0_bytes(m, W, NP));
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
         // pivot search (ballot) and which rows take the XOR; the pivot row is read once (broadcast)
         // into registers when it fits (WW = words per row incl. the syndrome word, compile time).
         int rank = 0;
+        unsigned used = 0;                           // bit i: row lane + 64 i already serves as a pivot row
         for (int k = 0; k < n && rank < P.rank; ++k) {   // :42-43 stops at m rows; rank(H) <= m
             const int c = idx[k];
             const int wi = c >> 5;
@@ -137,11 +140,12 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
                 const int r = base + lane;
                 const bool one = r < m && (A[r * RS + wi] & bit);
                 has |= (one ? 1u : 0u) << i;
-                const unsigned long long mask = __ballot(one && pivcol[r < m ? r : 0] < 0);
+                const unsigned long long mask = __ballot(one && !((used >> i) & 1u));
                 if (p < 0 && mask) p = base + (int)__builtin_ctzll(mask);
             }
             if (p < 0) continue;                     // column depends on earlier ones (:52-53)
             ++rank;
+            if (lane == (p & 63)) used |= 1u << (p >> 6);
             if constexpr (WW > 0) {
                 uint32_t prow[WW];
 #pragma unroll
