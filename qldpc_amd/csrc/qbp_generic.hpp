@@ -172,9 +172,15 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
             t[j] = tanh_half_msg<VARIANT>(q[j]);
             prod = (j == 0) ? t[0] : prod * t[j];
         }
+        // (t_safe, :122: |t| <= 1, so a product of at least 1e-15 has no factor below it -- one wave-uniform
+        // test instead of D compares and 2 D selects, as in the on-chip kernel)
+        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(prod) >= 1e-15)) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) t[j] = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+        }
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+            const double ts = t[j];
             double po = div_nr(prod, ts);
             po = __hiloint2double(__double2hiint(po) ^ (int)(sbit << 31), __double2loint(po));   // * sign
             const double x = atanh2(clip_unit<VARIANT>(po));
