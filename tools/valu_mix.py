@@ -20,6 +20,10 @@ loads, not from a committed profile:
 4. every other vector-ALU instruction in the loop is counted, by class (the classes the in-run
    microbenchmark tools/ubench/valu_rates.hip measures issue rates for).
 
+Limits: a build that re-reads a kernel argument inside the hot loop (the damped and min-sum instantiations do,
+for alpha / damping, under scalar-register pressure) defeats rule 3 -- the numbers are used, and checked, for the
+sum-product kernels only.
+
 The result is checked against hardware counters in profiles/ (SQ_INSTS_VALU and the per-class
 SQ_INSTS_VALU_* counters of the same kernel: see DESIGN.md section 4).
 """
