@@ -50,6 +50,9 @@
 #ifndef QBP_MC_PACK
 #define QBP_MC_PACK 0
 #endif
+#ifndef QBP_WORK_CHUNK_SMALL_CODES
+#define QBP_WORK_CHUNK_SMALL_CODES 1   // 0: at most eight syndromes per fetch whatever the code size (A/B)
+#endif
 #ifndef QBP_WORK_CHUNK_FIXED
 #define QBP_WORK_CHUNK_FIXED 0    // 1: eight syndromes per fetch from the work counter, always (A/B)
 #endif
@@ -353,7 +356,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         if (QBP_WORK_CHUNK_FIXED) return FORCE_FULL ? 1 : 8;                       // (A/B: round 1's rule)
         const long long rem = B - handed_out;
         const int share = rem >= 16 * total_slots ? 8 : rem >= 8 * total_slots ? 4 : rem >= 4 * total_slots ? 2 : 1;
-        return share > by_cost ? share : by_cost;
+        const int ch = share > by_cost ? share : by_cost;
+        // (small codes decode so many syndromes per microsecond -- [[72,12,6]]: 640 at p = 0.01 -- that eight per
+        // atomic still is 80 fetches/us on one word: two or four times as many while plenty remain)
+        const int f = QBP_WORK_CHUNK_SMALL_CODES ? (m <= 36 ? 4 : m <= 72 ? 2 : 1) : 1;
+        return (f > 1 && ch == 8 && rem >= (long long)16 * f * total_slots) ? 8 * f : ch;
     };
     long long b = lane_valid ? (long long)blockIdx.x * S + slot : B;
     bool active = b < B;
