@@ -57,12 +57,29 @@ enum {
                                  those of the first converged iteration (bench mode "M2") */
     QBP_FLAG_OSD0 = 2u,       /* qbp_mc_run only: trials BP does not converge on go through OSD-0
                                  (decoding/OSD.py) before classification, as paperResults.py:73-77 */
-    QBP_FLAG_PAIRWISE_COLSUM = 4u /* column sums in the order of np.sum over the gathered 1-D column,
+    QBP_FLAG_PAIRWISE_COLSUM = 4u, /* column sums in the order of np.sum over the gathered 1-D column,
                                  i.e. numpy's pairwise summation from 8 entries per column on: the
                                  loop form performBeliefPropagation (decoding/beliefPropagation.py:68).
                                  The dense forms (:129, rework/decoding.py) accumulate row by row =
                                  left to right, the default.  Only matrices with a column of weight
                                  >= 8 see a difference (they run on the general-H kernel). */
+    QBP_FLAG_DENSE_F_COLSUM = 8u, /* column sums in the order of np.sum(R, axis=0) on a FORTRAN-ordered dense
+                                 R: what the dense single-syndrome forms (decoding/beliefPropagation.py:129,
+                                 rework/decoding.py:61,:119,:173) compute when the caller's H is Fortran-ordered,
+                                 as the Hx of the reference's codes/ files is -- every (m, n) temporary inherits
+                                 the layout of `mask = H != 0`, a column is contiguous, and numpy reduces it
+                                 with its pairwise sum over all m entries (association by row index mod 8 and
+                                 by halves above 128 rows).  The batch form (decoding/beliefPropagationGPU.py:147)
+                                 works on C-ordered (B, m, n) arrays whatever H is: default order.
+                                 QBP_E_UNSUPPORTED when some column's association is not a left-to-right sum
+                                 of a reordering of its entries (possible from 4 entries per column on). */
+    QBP_FLAG_DENSE_F_COLSUM_ITER0 = 16u /* ... at iteration 0 only: the damped variants (rework/decoding.py:5,
+                                 :131) on a Fortran-ordered H of fewer than 32768 entries -- `Q_old = Q.copy()`
+                                 is C-ordered and C order wins in `damping * Q_new + (1 - damping) * Q_old` (:65,
+                                 :179) from then on (from 256 KiB numpy reuses the F-ordered temporary instead:
+                                 QBP_FLAG_DENSE_F_COLSUM).  Host-pointer entry point only; implemented for
+                                 the case where iteration 0 cannot depend on the order (uniform priors, checks
+                                 of equal weight, columns of at most 3 entries), else QBP_E_UNSUPPORTED. */
 };
 #define QBP_MC_OSD_MAX_TRIALS (1 << 20) /* per qbp_mc_run call with QBP_FLAG_OSD0 (record buffers) */
 
@@ -87,6 +104,17 @@ void qbp_destroy(qbp_handle* h);
  */
 int qbp_plan(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n, int32_t info[8],
              int32_t* tab_var, uint16_t* tab_nbr, uint32_t* tab_writer);
+
+/*
+ * Host-only: the order in which the kernels add up the check->variable messages of every column
+ * (left to right).  col_order 0: ascending check -- np.sum(R, axis=0) on a C-ordered dense R
+ * (decoding/beliefPropagation.py:129) adds row by row; col_order 1: the association numpy's pairwise sum
+ * gives the column of a Fortran-ordered R (QBP_FLAG_DENSE_F_COLSUM).  Outputs: col_ptr [n+1] and col_edge [E]
+ * (CSR edge ids, column by column, in summation order).  QBP_E_UNSUPPORTED when col_order 1 is not a
+ * left-to-right sum for some column.
+ */
+int qbp_column_order(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n, int32_t col_order,
+                     int32_t* col_ptr, int32_t* col_edge);
 
 /*
  * Decode B syndromes (host buffers).

@@ -26,6 +26,33 @@ VARIANT_DAMPED_SP = 1       # rework/decoding.py:131-191
 VARIANT_MIN_SUM = 2         # rework/decoding.py:5-75
 FLAG_FORCE_FULL = 1
 FLAG_PAIRWISE_COLSUM = 4   # column sums as np.sum(R[checks_v, v]) (loop form, beliefPropagation.py:68)
+FLAG_LIBM_MATH = 8         # host libm tanh/atanh instead of numpy's own kernels (np_math.h)
+FLAG_DENSE_F_COLSUM = 16   # column sums as np.sum(R, axis=0) on Fortran-ordered R (dense forms, F-ordered H)
+FLAG_DENSE_F_COLSUM_ITER0 = 32   # ... at iteration 0 only (damped variants, F-ordered H below 256 KiB)
+
+
+def colsum_flags(fn: str, H) -> int:
+    """Order in which the reference function `fn` adds up a column of check->variable messages,
+    given the caller's H -- numpy semantics, measured on numpy 2.2.6:
+
+    * loop form (beliefPropagation.py:68): np.sum of the gathered column -> FLAG_PAIRWISE_COLSUM;
+    * batch form (beliefPropagationGPU.py:147): C-ordered (B, m, n) temporaries -> row by row (0);
+    * dense single-syndrome forms: row by row for a C-ordered H; for a Fortran-ordered H (the Hx of the
+      reference's code files) every (m, n) temporary is F-ordered and np.sum(R, axis=0) is numpy's
+      pairwise sum down the dense column -> FLAG_DENSE_F_COLSUM; the damped variants copy Q to C order
+      (`Q_old = Q.copy()`), after which C order wins from iteration 1 on -> ..._ITER0, unless the arrays
+      reach numpy's temporary-elision size (256 KiB), where the F-ordered temporary is reused.
+    """
+    if fn in ("loop3", "loop"):
+        return FLAG_PAIRWISE_COLSUM
+    if fn == "batch":
+        return 0
+    f_order = isinstance(H, np.ndarray) and H.ndim == 2 and H.flags["F_CONTIGUOUS"] and not H.flags["C_CONTIGUOUS"]
+    if not f_order:
+        return 0
+    if fn in ("minsum", "sym") and H.shape[0] * H.shape[1] * 8 < 256 * 1024:
+        return FLAG_DENSE_F_COLSUM_ITER0
+    return FLAG_DENSE_F_COLSUM
 
 
 def build(force: bool = False) -> str:

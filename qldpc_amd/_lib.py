@@ -21,6 +21,8 @@ SUM_PRODUCT, DAMPED_SP, MIN_SUM = 0, 1, 2
 FLAG_FORCE_FULL = 1
 FLAG_OSD0 = 2
 FLAG_PAIRWISE_COLSUM = 4     # np.sum order of the loop form (beliefPropagation.py:68)
+FLAG_DENSE_F_COLSUM = 8      # np.sum(R, axis=0) order of the dense forms on a Fortran-ordered H (include/qbp.h)
+FLAG_DENSE_F_COLSUM_ITER0 = 16   # ... at iteration 0 only (damped variants, F-ordered H below 256 KiB)
 MC_OSD_MAX_TRIALS = 1 << 20
 NUM_COUNTERS = 12
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",
@@ -40,6 +42,7 @@ SIGNATURES = {
     "qbp_create": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "qbp_destroy": (None, [_VP]),
     "qbp_plan": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),
+    "qbp_column_order": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "qbp_decode_batch": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_double,
                                    C.c_double, C.c_double, C.c_uint32, _VP, _VP, _VP, _VP]),
     "qbp_decode_batch_device": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_int32,
@@ -68,7 +71,11 @@ SIGNATURES = {
 
 
 class QbpError(RuntimeError):
-    pass
+    """A libqbp call failed; ``code`` is the QBP_E_* value of include/qbp.h."""
+    code = 0
+
+
+E_UNSUPPORTED = -4
 
 
 _lib = None
@@ -114,7 +121,9 @@ def load():
 
 def _check(rc):
     if rc != 0:
-        raise QbpError(f"libqbp error {rc}: {load().qbp_last_error().decode()}")
+        err = QbpError(f"libqbp error {rc}: {load().qbp_last_error().decode()}")
+        err.code = int(rc)
+        raise err
 
 
 def _ptr(a):

@@ -191,19 +191,67 @@ def _check_iter(maxIter):
     return int(maxIter)
 
 
+# numpy's temporary elision (an operand that is an unreferenced temporary of at least this size is reused as the
+# output of the next operation, keeping ITS memory order): numpy/_core/src/multiarray/temp_elide.c
+_NPY_MIN_ELIDE_BYTES = 256 * 1024
+_warned_order = set()
+
+
+def dense_colsum_flags(H, damped=False):
+    """Order in which a DENSE single-syndrome form of the reference adds up a column of check->variable
+    messages (``np.sum(R, axis=0)``, decoding/beliefPropagation.py:129, rework/decoding.py:61 / :119 / :173),
+    as a ``qbp_decode_batch`` flag.  It depends on the memory order of the caller's H, because every (m, n)
+    temporary of those functions inherits the order of ``mask = H != 0``:
+
+    * C order (lists, scipy-sparse input, ``np.hstack`` / ``np.kron`` products such as the space-time
+      matrices): rows are added one after the other -- 0;
+    * Fortran order -- the ``Hx`` of the reference's ``codes/*.npz`` is stored that way: a column is contiguous
+      and numpy adds it with its pairwise sum over all m entries -- ``FLAG_DENSE_F_COLSUM``;
+    * the damped variants (``damped=True``, rework/decoding.py:5 and :131) copy Q to C order
+      (``Q_old = Q.copy()``), after which C order wins in ``damping * Q_new + (1 - damping) * Q_old`` from
+      iteration 1 on -- ``FLAG_DENSE_F_COLSUM_ITER0`` -- unless the arrays reach numpy's temporary-elision size,
+      where the F-ordered temporary ``damping * Q_new`` is reused as the result.
+
+    The loop form sums gathered columns (``FLAG_PAIRWISE_COLSUM``) and the batch form works on C-ordered
+    (B, m, n) arrays: neither depends on H's order.  Measured on numpy 2.2.6; DESIGN.md section 2."""
+    if not isinstance(H, np.ndarray) or H.ndim != 2 or H.shape[0] < 2 or H.shape[1] < 2:
+        return 0
+    if not abs(H.strides[0]) < abs(H.strides[1]):
+        return 0
+    if damped and H.shape[0] * H.shape[1] * 8 < _NPY_MIN_ELIDE_BYTES:
+        return _lib.FLAG_DENSE_F_COLSUM_ITER0
+    return _lib.FLAG_DENSE_F_COLSUM
+
+
 def decode_one(H, syndrome, initialBelief, maxIter, variant=_lib.SUM_PRODUCT, alpha=1.0,
                damping=1.0, clip_llr=20.0, flags=0):
     """(hard int8[n], converged bool, llr float64[n], iteration int) for one syndrome."""
     dec = decoder_for(H)
     syn = _syndromes(syndrome, dec.m, batch=False)
-    hard, conv, iters, llr = dec.decode(syn[None, :].view(np.uint8), _prior(initialBelief, dec.n),
-                                        _check_iter(maxIter), variant, alpha, damping, clip_llr, flags)
+    args = (syn[None, :].view(np.uint8), _prior(initialBelief, dec.n), _check_iter(maxIter), variant,
+            alpha, damping, clip_llr)
+    try:
+        hard, conv, iters, llr = dec.decode(*args, flags)
+    except _lib.QbpError as e:
+        order = flags & (_lib.FLAG_DENSE_F_COLSUM | _lib.FLAG_DENSE_F_COLSUM_ITER0)
+        if not order or e.code != _lib.E_UNSUPPORTED:
+            raise
+        # a column-sum association the kernels cannot express (include/qbp.h): row-by-row sums instead --
+        # hard decisions are unaffected in every case tested, LLRs may differ from the reference's in the last
+        # ulps.  Said once per matrix shape.
+        key = (dec.m, dec.n, order)
+        if key not in _warned_order:
+            _warned_order.add(key)
+            import warnings
+            warnings.warn(f"qldpc_amd: {e}; using row-by-row column sums (LLRs may differ from the "
+                          "reference's in the last ulps)", RuntimeWarning, stacklevel=3)
+        hard, conv, iters, llr = dec.decode(*args, flags & ~order)
     return hard[0].astype(np.int8), bool(conv[0]), llr[0], int(iters[0])
 
 
 def performBeliefPropagationFast(H, syndrome, initialBelief, verbose=True, maxIter=50):
     """decoding/beliefPropagation.py:88-144."""
-    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter)
+    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter, flags=dense_colsum_flags(H))
     if conv and verbose:
         print(f"Error found at iteration {it}: {hard}")                      # :141
     return hard, conv, llr
@@ -232,7 +280,7 @@ def performBeliefPropagation(H, syndrome, initialBelief, verbose=True, plotPath=
 
 def performBeliefPropagationGPU(H, syndrome, initialBelief, verbose=False, maxIter=50):
     """decoding/beliefPropagationGPU.py:22-78."""
-    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter)
+    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter, flags=dense_colsum_flags(H))
     if conv and verbose:
         print(f"Error found at iteration {it}")                              # :73
     return hard, conv, llr

@@ -82,6 +82,9 @@ def load_code(name: str) -> Code:
     if name == "steane":
         return Code("steane", STEANE_H.copy(), STEANE_H.copy(), None, None, None)
     Hx, Hz = bb_matrices(name)
+    # memory order as in the reference's files (Hx Fortran-ordered, Hz C-ordered): the order in which the
+    # reference's dense decoders add up column sums follows it (qldpc_amd.bp.dense_colsum_flags)
+    Hx = np.asfortranarray(Hx)
     n = Hx.shape[1]
     with np.load(_DATA) as d:
         k = int(d[f"{name}/k"])

@@ -160,6 +160,14 @@ struct qbp_handle {
     DevBuf<uint32_t> d_hbits;
     DevBuf<int32_t> d_row_ptr, d_col_idx;
     DevBuf<uint8_t> d_sol;
+    // the order-dependent tables once more, for column sums in the order of a Fortran-ordered dense R
+    // (QBP_FLAG_DENSE_F_COLSUM; built at the first such call)
+    struct ColumnOrderTables {
+        int state = 0;               // 0 not built, 1 ready, -1 not expressible (QBP_E_UNSUPPORTED)
+        DevBuf<uint16_t> tab_nbr;
+        DevBuf<uint32_t> tab_writer;
+        DevBuf<int32_t> col_edge, sedge, vpos, vrow;
+    } f_order;
     // Monte-Carlo + OSD failure records
     DevBuf<long long> d_fail_list;
     DevBuf<unsigned long long> d_fail_count;
@@ -177,7 +185,8 @@ using qbp::LaunchCfg;
 size_t fused_lds_bytes(int dc, int m, int n, int S, bool two_copies = false, bool r0_table = false)
 {
     const size_t slot_stride = (size_t)dc * m + 2;
-    size_t lds = (two_copies ? (size_t)qbp::FUSED_R2_OFF_BYTES : 0) + (r0_table ? (size_t)2 * dc * m * 8 : 0) +
+    size_t lds = (size_t)qbp::NP_LDS_BYTES +      // tables of tanh / arctanh (qbp_math.hpp), at the start
+                 (two_copies ? (size_t)qbp::FUSED_R2_OFF_BYTES : 0) + (r0_table ? (size_t)2 * dc * m * 8 : 0) +
                  ((size_t)S * slot_stride + (size_t)dc * m + 3 * (size_t)S) * 8 +
                  (6 * (size_t)S + 1 + (size_t)S * qbp::NUM_COUNTERS + (size_t)dc * m) * 4 +
                  2 * (size_t)S * (((size_t)n + 3) / 4) * 4;     // err_lds[2][S][n4] (Monte-Carlo builds)
@@ -204,7 +213,74 @@ struct HostTables {
     int col_off[qbp::STREAM_MAX_COL_CLASS + 3] = {0}, col_edge_base[qbp::STREAM_MAX_COL_CLASS + 2] = {0};
 };
 
-int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, HostTables& T)
+// Order in which np.sum(R, axis=0) adds up the non-zero entries of one column of a FORTRAN-ordered dense
+// (m, n) array R -- which is what the reference's dense single-syndrome forms reduce whenever the caller's
+// H is Fortran-ordered, as the Hx of its code files is (every (m, n) temporary inherits the layout of
+// `mask = H != 0`).  The column is contiguous then and numpy runs pairwise_sum over all m entries, zeros
+// included (numpy/_core/src/umath/loops_utils.h.src): fewer than 8 rows left to right; up to 128 rows eight
+// running sums by row mod 8, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the m mod 8 trailing rows;
+// more rows split in halves (the first a multiple of 8) recursively.  x + 0.0 is exact, so only the
+// association of the non-zero entries matters: simulated here symbolically.  Returns false when that
+// association is not a left-to-right sum of SOME ordering of the entries (possible from 4 entries on:
+// (a + b) + (c + d)); `order` = that ordering as indices into the column's ascending-check list.
+struct FSumNode { int leaf, l, r; };
+static int fsum_add(std::vector<FSumNode>& pool, int a, int b)
+{
+    if (a < 0) return b;
+    if (b < 0) return a;
+    pool.push_back({-1, a, b});
+    return (int)pool.size() - 1;
+}
+static int fsum_range(std::vector<FSumNode>& pool, const std::vector<int>& rows, int lo, int hi)
+{
+    const int n = hi - lo;
+    int a = 0;
+    while (a < (int)rows.size() && rows[a] < lo) ++a;
+    int b = a;
+    while (b < (int)rows.size() && rows[b] < hi) ++b;
+    if (a == b) return -1;
+    if (n < 8) {
+        int res = -1;
+        for (int i = a; i < b; ++i) res = fsum_add(pool, res, i);
+        return res;
+    }
+    if (n <= 128) {
+        int r[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        const int body = n - n % 8;
+        int i = a;
+        for (; i < b && rows[i] - lo < body; ++i) r[(rows[i] - lo) % 8] = fsum_add(pool, r[(rows[i] - lo) % 8], i);
+        int res = fsum_add(pool, fsum_add(pool, fsum_add(pool, r[0], r[1]), fsum_add(pool, r[2], r[3])),
+                           fsum_add(pool, fsum_add(pool, r[4], r[5]), fsum_add(pool, r[6], r[7])));
+        for (; i < b; ++i) res = fsum_add(pool, res, i);
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return fsum_add(pool, fsum_range(pool, rows, lo, lo + n2), fsum_range(pool, rows, lo + n2, hi));
+}
+static bool fsum_flatten(const std::vector<FSumNode>& pool, int node, std::vector<int>& out)
+{
+    const FSumNode& x = pool[node];
+    if (x.leaf >= 0) { out.push_back(x.leaf); return true; }
+    const bool ll = pool[x.l].leaf >= 0, rl = pool[x.r].leaf >= 0;
+    if (rl) { if (!fsum_flatten(pool, x.l, out)) return false; out.push_back(pool[x.r].leaf); return true; }
+    if (ll) { if (!fsum_flatten(pool, x.r, out)) return false; out.push_back(pool[x.l].leaf); return true; }
+    return false;
+}
+static bool dense_f_column_order(const std::vector<int>& rows, int m, std::vector<int>& order)
+{
+    std::vector<FSumNode> pool;
+    for (int i = 0; i < (int)rows.size(); ++i) pool.push_back({i, -1, -1});
+    order.clear();
+    if (rows.empty()) return true;
+    const int root = fsum_range(pool, rows, 0, m);
+    return fsum_flatten(pool, root, order) && order.size() == rows.size();
+}
+
+// col_order: 0 = every column's entries in ascending check order (np.sum(R, axis=0) of a C-ordered R adds row
+// by row); 1 = the order of a Fortran-ordered R (dense_f_column_order).  All kernels add a column's messages
+// left to right in the order of these tables.
+int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, HostTables& T, int col_order = 0)
 {
     if (!row_ptr || m < 0 || n < 0) return fail(QBP_E_INVALID, "bad matrix arguments");
     if (m == 0 || n == 0) return fail(QBP_E_INVALID, "empty matrix (%d x %d)", m, n);
@@ -228,6 +304,21 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
         T.max_col = std::max(T.max_col, (int)cols[v].size());
         if (cols[v].empty()) T.iso.push_back(v);
     }
+    if (col_order == 1) {
+        std::vector<int> rows, order;
+        for (int v = 0; v < n; ++v) {
+            rows.clear();
+            for (const auto& ce : cols[v]) rows.push_back(ce.first);
+            if (!dense_f_column_order(rows, m, order))
+                return fail(QBP_E_UNSUPPORTED,
+                            "column %d (%zu entries): numpy's pairwise sum over a Fortran-ordered dense column "
+                            "associates them as a balanced tree, which the kernels' left-to-right sums cannot "
+                            "express", v, rows.size());
+            std::vector<std::pair<int, int>> perm;
+            for (int i : order) perm.push_back(cols[v][i]);
+            cols[v] = perm;
+        }
+    }
     if (T.max_row <= DC_SMALL && T.max_col <= DV_SMALL) { T.dc = DC_SMALL; T.dv = DV_SMALL; }
     else { T.dc = DC_WIDE; T.dv = DV_WIDE; }
     T.fused_ok = (m <= 1024) && T.max_row <= T.dc && T.max_col <= T.dv &&
@@ -246,7 +337,7 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
                 const auto& col = cols[v];
                 for (size_t k = 0; k < col.size(); ++k)
                     T.tab_nbr[((size_t)j * DV + k) * m + c] = (uint16_t)(col[k].second * m + col[k].first);
-                if (col[0].first == c) T.tab_writer[c] |= 1u << j;
+                if (col[0].first == c) T.tab_writer[c] |= 1u << j;     // (one lane per variable writes its outputs)
             }
         }
     }
@@ -411,16 +502,67 @@ int check_decode_args(qbp_handle* h, long long B, int max_iter, int variant, boo
     return QBP_OK;
 }
 
-void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg)
+void fill_static(qbp_handle* h, FusedParams& P, const LaunchCfg& cfg, bool f_order = false)
 {
     P.m = h->m; P.n = h->n;
     P.S = cfg.S; P.slot_stride = cfg.slot_stride;
     P.r0_table = cfg.r0_table;
     P.padded = h->padded ? 1 : 0;
     P.n_words4 = (h->n + 3) / 4;
-    P.tab_var = h->d_tab_var.p; P.tab_nbr = h->d_tab_nbr.p; P.tab_writer = h->d_tab_writer.p;
+    P.tab_var = h->d_tab_var.p;
+    P.tab_nbr = f_order ? h->f_order.tab_nbr.p : h->d_tab_nbr.p;
+    P.tab_writer = f_order ? h->f_order.tab_writer.p : h->d_tab_writer.p;
     P.iso_vars = h->d_iso.p; P.n_iso = h->n_iso;
     P.work_counter = h->d_work_counter.p;
+}
+
+// Column-sum order of a decode call (include/qbp.h, QBP_FLAG_DENSE_F_COLSUM*): clears the two flag bits and
+// sets *f_order when the launch has to use the Fortran-order tables (built and uploaded at the first such call).
+int resolve_column_order(qbp_handle* h, unsigned& flags, const double* host_prior, int* mode)
+{
+    *mode = 0;                               // 0 row by row, 1 Fortran order, 2 Fortran order at iteration 0 only
+    const unsigned want = flags & (QBP_FLAG_DENSE_F_COLSUM | QBP_FLAG_DENSE_F_COLSUM_ITER0);
+    flags &= ~(QBP_FLAG_DENSE_F_COLSUM | QBP_FLAG_DENSE_F_COLSUM_ITER0);
+    if (!want) return QBP_OK;
+    if (want == (QBP_FLAG_DENSE_F_COLSUM | QBP_FLAG_DENSE_F_COLSUM_ITER0) || (flags & QBP_FLAG_PAIRWISE_COLSUM))
+        return fail(QBP_E_INVALID, "at most one column-sum order flag per call");
+    if (want == QBP_FLAG_DENSE_F_COLSUM_ITER0 && host_prior) {
+        // Iteration 0 does not depend on the order when all of a column's messages have the same magnitude r
+        // -- equal priors on every edge and checks of equal weight -- and a column has at most three of them:
+        // every partial sum is k r with |k| <= 3, and k r is exact for |k| <= 2 and rounded once, from the
+        // exact value, for |k| = 3.  That is the reference's own use (rework/Alvarado.py, rework/main.py:
+        // uniform priors on the code files' Hx) and needs no second table set in the launch.
+        bool same = h->max_col_deg <= 3;
+        const int d0 = h->m > 0 ? h->row_ptr[1] - h->row_ptr[0] : 0;
+        for (int c = 0; same && c < h->m; ++c) same = (h->row_ptr[c + 1] - h->row_ptr[c]) == d0;
+        if (same && h->E > 0) {
+            const double p0 = host_prior[h->col_idx[0]];
+            for (int e = 0; same && e < h->E; ++e) same = host_prior[h->col_idx[e]] == p0;
+        }
+        if (same) return QBP_OK;             // = row-by-row tables
+    }
+    auto& F = h->f_order;
+    if (F.state == 0) {
+        HostTables T;
+        const int rc = build_tables(h->row_ptr.data(), h->col_idx.data(), h->m, h->n, T, 1);
+        if (rc == QBP_E_UNSUPPORTED) { F.state = -1; return rc; }
+        if (rc) return rc;
+        hipError_t e1 = hipSuccess;
+        auto up = [&](auto& buf, const auto& vec) {
+            if (e1 != hipSuccess) return;
+            e1 = buf.reserve(vec.size());
+            if (e1 == hipSuccess && !vec.empty())
+                e1 = hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice);
+        };
+        if (T.fused_ok) { up(F.tab_nbr, T.tab_nbr); up(F.tab_writer, T.tab_writer); }
+        up(F.col_edge, T.col_edge); up(F.sedge, T.sedge); up(F.vpos, T.vpos); up(F.vrow, T.vrow);
+        if (e1 != hipSuccess) return fail(QBP_E_HIP, "upload of the column-order tables failed: %s", hipGetErrorString(e1));
+        F.state = 1;
+    }
+    if (F.state < 0)
+        return fail(QBP_E_UNSUPPORTED, "the Fortran-order column sums of this matrix are not a left-to-right sum");
+    *mode = want == QBP_FLAG_DENSE_F_COLSUM ? 1 : 2;
+    return QBP_OK;
 }
 
 }  // namespace
@@ -486,7 +628,7 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
                           int max_iter, int variant, double alpha, double damping, double clip_llr,
                           unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
                           double* d_llr, double* d_dump, int dump_iter, double dump_div, hipStream_t s,
-                          const qbp::GenericParams* mc = nullptr)
+                          const qbp::GenericParams* mc = nullptr, int col_mode = 0)
 {
     if ((flags & QBP_FLAG_PAIRWISE_COLSUM) && h->max_col_deg > qbp::GENERIC_PAIRWISE_MAX_COL)
         return fail(QBP_E_UNSUPPORTED, "QBP_FLAG_PAIRWISE_COLSUM supports column weights up to %d (got %d)",
@@ -530,7 +672,11 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     }
     std::copy(std::begin(h->row_off), std::end(h->row_off), G.row_off);
     std::copy(std::begin(h->row_base), std::end(h->row_base), G.row_base);
-    G.svar = h->d_svar.p; G.vpos = h->d_vpos.p; G.vrow = h->d_vrow.p; G.lcol_ptr = h->d_lcol_ptr.p;
+    G.svar = h->d_svar.p; G.lcol_ptr = h->d_lcol_ptr.p;
+    G.vpos = col_mode == 1 ? h->f_order.vpos.p : h->d_vpos.p;
+    G.vrow = col_mode == 1 ? h->f_order.vrow.p : h->d_vrow.p;
+    G.vpos0 = col_mode == 2 ? h->f_order.vpos.p : nullptr;      // Fortran order at iteration 0 only
+    G.vrow0 = col_mode == 2 ? h->f_order.vrow.p : nullptr;
     std::copy(std::begin(h->col_off), std::end(h->col_off), G.col_off);
     std::copy(std::begin(h->gcol_base), std::end(h->gcol_base), G.col_base);
     std::copy(std::begin(h->rpad_off), std::end(h->rpad_off), G.rpad_off);
@@ -712,6 +858,18 @@ try {
 }
 QBP_ABI_CATCH
 
+int qbp_column_order(const int32_t* row_ptr, const int32_t* col_idx, int32_t m, int32_t n, int32_t col_order,
+                     int32_t* col_ptr, int32_t* col_edge)
+try {
+    HostTables T;
+    int rc = build_tables(row_ptr, col_idx, m, n, T, col_order);
+    if (rc) return rc;
+    if (col_ptr) std::memcpy(col_ptr, T.col_ptr.data(), ((size_t)n + 1) * sizeof(int32_t));
+    if (col_edge && row_ptr[m] > 0) std::memcpy(col_edge, T.col_edge.data(), (size_t)row_ptr[m] * sizeof(int32_t));
+    return QBP_OK;
+}
+QBP_ABI_CATCH
+
 void qbp_destroy(qbp_handle* h)
 {
     if (!h) return;
@@ -732,6 +890,8 @@ void qbp_destroy(qbp_handle* h)
     h->d_epos.release(); h->d_cpos.release(); h->d_long_edge_row.release(); h->d_wsL.release();
     h->d_vpos.release(); h->d_vrow.release(); h->d_lcol_ptr.release(); h->d_prior_sorted.release();
     h->d_hbits.release(); h->d_row_ptr.release(); h->d_col_idx.release(); h->d_sol.release();
+    h->f_order.tab_nbr.release(); h->f_order.tab_writer.release(); h->f_order.col_edge.release();
+    h->f_order.sedge.release(); h->f_order.vpos.release(); h->f_order.vrow.release();
     h->d_osd_At.release(); h->d_osd_piv.release(); h->d_osd_idx.release(); h->d_osd_sol.release();
     h->d_osd_keys.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
@@ -742,7 +902,7 @@ void qbp_destroy(qbp_handle* h)
 static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double* d_prior, int64_t B,
                          int max_iter, int variant, double alpha, double damping, double clip_llr,
                          unsigned flags, uint8_t* d_hard, uint8_t* d_converged, int32_t* d_iters,
-                         double* d_llr, hipStream_t s)
+                         double* d_llr, hipStream_t s, bool f_order = false)
 {
     // streaming kernel: one lane per syndrome, messages [edge][syndrome] in a global workspace;
     // long batches go through in chunks that keep the workspace under 16 GiB
@@ -770,8 +930,10 @@ static int stream_launch(qbp_handle* h, const uint8_t* d_syndromes, const double
         const long long lanes = std::min<long long>(Bc, B - b0);
         const unsigned grid = (unsigned)((lanes + 255) / 256);
         h->last_threads = 256; h->last_lds = 0; h->last_grid = (int)grid;
-HIP_TRY(qbp::launch_stream(variant, grid, P, h->d_col_idx.p, h->d_col_ptr.p, h->d_col_edge.p, d_prior,
-                                   h->d_srow.p, h->d_srow_e0.p, h->d_srow_deg.p, h->d_svar.p, h->d_sedge.p, s));
+        HIP_TRY(qbp::launch_stream(variant, grid, P, h->d_col_idx.p, h->d_col_ptr.p,
+                                   f_order ? h->f_order.col_edge.p : h->d_col_edge.p, d_prior,
+                                   h->d_srow.p, h->d_srow_e0.p, h->d_srow_deg.p, h->d_svar.p,
+                                   f_order ? h->f_order.sedge.p : h->d_sedge.p, s));
     }
     return QBP_OK;
 }
@@ -789,6 +951,10 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     DeviceScope on_device(h->device);
     HIP_TRY(on_device.err);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    int col_mode = 0;                        // column sums in the order of a Fortran-ordered dense R
+    rc = resolve_column_order(h, flags, nullptr, &col_mode);
+    if (rc) return rc;
+    const bool f_order = col_mode == 1;
     // kernel choice: the on-chip kernel when the matrix fits; otherwise one workgroup per syndrome
     // (general-H), except for small graphs in batches that fill the chip with one LANE per syndrome,
     // where the streaming kernel is ahead (tools/bench_generic.py: [[288,12,18]], 262144 syndromes:
@@ -801,18 +967,19 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     // numpy's pairwise column sums only differ from 8 entries per column on; those matrices never
     // fit the on-chip kernel, and only the general-H kernel implements that order
     if ((flags & QBP_FLAG_PAIRWISE_COLSUM) && h->max_col_deg >= 8) kernel = 2;
+    if (col_mode == 2) kernel = 2;           // two column orders in one launch: the general-H kernel only
     h->last_kernel = kernel;
     if (kernel == 3)
         return stream_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr, flags,
-                             d_hard, d_converged, d_iters, d_llr, s);
+                             d_hard, d_converged, d_iters, d_llr, s, f_order);
     if (kernel == 2)
         return generic_launch(h, d_syndromes, d_prior, B, max_iter, variant, alpha, damping, clip_llr,
-                              flags, d_hard, d_converged, d_iters, d_llr, nullptr, 0, 1.0, s);
+                              flags, d_hard, d_converged, d_iters, d_llr, nullptr, 0, 1.0, s, nullptr, col_mode);
     LaunchCfg cfg;
     rc = make_cfg(h, B, &cfg, (flags & QBP_FLAG_FORCE_FULL) != 0, false);
     if (rc) return rc;
     FusedParams P{};
-    fill_static(h, P, cfg);
+    fill_static(h, P, cfg, f_order);
     P.syndromes = d_syndromes; P.prior = d_prior; P.B = B;
     P.max_iter = max_iter; P.flags = flags;
     P.alpha = alpha; P.damping = damping; P.clip_llr = clip_llr;
@@ -837,6 +1004,13 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
     if (!syndromes || !prior) return fail(QBP_E_INVALID, "null input pointer");
     for (int v = 0; v < h->n; ++v)
         if (prior[v] != prior[v]) return fail(QBP_E_INVALID, "prior[%d] is NaN (+-inf are legal)", v);
+    if (flags & QBP_FLAG_DENSE_F_COLSUM_ITER0) {     // (the shortcut is judged on the host copy of the priors)
+        int mode = 0;
+        unsigned fl = flags;
+        rc = resolve_column_order(h, fl, prior, &mode);
+        if (rc) return rc;
+        if (mode == 0) flags = fl;                   // iteration 0 cannot depend on the order: plain call
+    }
     DeviceScope on_device(h->device);
     HIP_TRY(on_device.err);
     const size_t m = h->m, n = h->n, b = (size_t)B;

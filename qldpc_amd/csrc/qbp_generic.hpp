@@ -70,6 +70,10 @@ struct GenericParams {
     const int32_t* svar;        // [n]
     const int32_t* vpos;        // [E]
     const int32_t* vrow;        // [E]
+    // the same two tables with every column's entries in another summation order, used at iteration 0 only
+    // (QBP_FLAG_DENSE_F_COLSUM_ITER0: include/qbp.h); null = one order throughout
+    const int32_t* vpos0;
+    const int32_t* vrow0;
     const int32_t* lcol_ptr;    // [number of long columns + 1], absolute offsets into vpos / vrow
     int col_off[GENERIC_MAX_COL_CLASS + 3];    // class boundaries in svar (weights 0 .. 4, > 4)
     int col_base[GENERIC_MAX_COL_CLASS + 2];
@@ -127,7 +131,8 @@ __host__ __device__ inline size_t generic_lds_words(int m)
 __host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool lds_msgs, bool lds_tables,
                                                     int r_split = 0)
 {
-    return (lds_msgs ? (size_t)16 * (size_t)E : (size_t)8 * (size_t)r_split) + generic_lds_words(m) * 4 +
+    return (size_t)NP_LDS_BYTES +      // tables of tanh / arctanh (qbp_math.hpp), at the start
+           (lds_msgs ? (size_t)16 * (size_t)E : (size_t)8 * (size_t)r_split) + generic_lds_words(m) * 4 +
            (lds_tables ? (size_t)8 * (size_t)n + (size_t)4 * (size_t)E : 0);
 }
 
@@ -136,7 +141,7 @@ __host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool ld
 // (rework/decoding.py:168-169 returns R before the alpha scaling).
 template <int VARIANT, int D>
 __device__ __forceinline__ void generic_row_update(const double (&q)[D], double (&r)[D], unsigned sbit,
-                                                   double alpha, bool scale)
+                                                   double alpha, bool scale, const double* np_tab)
 {
     if constexpr (VARIANT == 2) {
         double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
@@ -169,7 +174,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
         double prod = 1.0;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            t[j] = tanh_half_msg<VARIANT>(q[j]);
+            t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);
             prod = (j == 0) ? t[0] : prod * t[j];
         }
         // (t_safe, :122: |t| <= 1, so a product of at least 1e-15 has no factor below it -- one wave-uniform
@@ -183,7 +188,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
             const double ts = t[j];
             double po = div_nr(prod, ts);
             po = __hiloint2double(__double2hiint(po) ^ (int)(sbit << 31), __double2loint(po));   // * sign
-            const double x = atanh2(clip_unit<VARIANT>(po));
+            const double x = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
             r[j] = (VARIANT == 1 && scale) ? x * alpha : x;
         }
     }
@@ -264,8 +269,11 @@ template <int VARIANT, bool MC, int MEM>
 __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
     constexpr bool LDSMSG = MEM == GENERIC_MEM_LDS;
-    extern __shared__ double gsm[];
+    extern __shared__ double gsm_all[];
+    const double* const np_tab = gsm_all;
+    double* const gsm = gsm_all + NP_LDS_DOUBLES;
     const int tid = threadIdx.x, nt = blockDim.x;
+    np_tables_to_lds(gsm_all, tid, nt);           // (published by the first barrier of the syndrome loop)
     const int lane = tid & 63;
     const int m = P.m, n = P.n, E = P.E;
     constexpr int RC = GENERIC_MAX_ROW_CLASS, CC = GENERIC_MAX_COL_CLASS;
@@ -422,11 +430,14 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         __syncthreads();
         const int syn_weight = unsat[0];      // unsatisfied checks of the all-zero candidate
 
+        // column tables of the current iteration (another order at iteration 0: GenericParams::vpos0)
+        const int32_t* vp = vpos_t;
+        const int32_t* vr = P.vrow;
         // Posterior value of a long column (weight > 4) from the current R
         auto long_column_value = [&](int i, const int32_t*& pos, int& deg) {
             const int k0 = P.lcol_ptr[i];
             deg = P.lcol_ptr[i + 1] - k0;
-            pos = vpos_t + k0;
+            pos = vp + k0;
             double s = 0.0;
             if (pairwise && deg >= 8) {
                 s = np_pairwise_gather<GENERIC_PAIRWISE_LEVELS>(Rload, pos, deg);
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 } else if (x < first_lcol) {
                     int D, cnt, o;
                     generic_col_class(P, x, D, cnt, o);
-                    const int32_t* const pos = vpos_t + o;
+                    const int32_t* const pos = vp + o;
                     double s = 0.0;
                     for (int j = 0; j < D; ++j) {
                         const double r = Rload(pos[(size_t)j * cnt]);
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const int base = P.row_base[DD] + i;                                       \
                         double q[DD], r[DD];                                                       \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = QBP_GEN_QLOAD(base + j * cnt);   \
-                        generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale);               \
+                        generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale, np_tab);               \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) Rstore(base + j * cnt, r[j]);   \
                     }                                                                              \
                 } break;
@@ -550,7 +561,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             if (n_long > 0) {                                           // uniform
                 double* const L = P.wsL + (size_t)blockIdx.x * 3 * n_long;
                 if constexpr (VARIANT != 2) {
-                    for (int k = tid; k < n_ledges; k += nt) Rstore(lbase + k, tanh_half_msg<VARIANT>(Q[lbase + k]));
+                    for (int k = tid; k < n_ledges; k += nt) Rstore(lbase + k, tanh_half_msg<VARIANT>(Q[lbase + k], np_tab));
                     __syncthreads();
                 }
                 for (int i = tid; i < n_long; i += nt) {
@@ -604,7 +615,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
                         double po = div_nr(L[3 * i], ts);
                         po = sbit ? -po : po;
-                        const double x = atanh2(clip_unit<VARIANT>(po));
+                        const double x = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
                         Rstore(lbase + k, (VARIANT == 1 && scale) ? x * P.alpha : x);
                     }
                 }
@@ -616,6 +627,8 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 break;
             }
             // ================= variable step (:129-136) + incremental syndrome test (:137-139) ====
+            vp = (it == 0 && P.vpos0) ? P.vpos0 : vpos_t;
+            vr = (it == 0 && P.vrow0) ? P.vrow0 : P.vrow;
             const int p = it & 1;
             unsigned* const pbuf = par + p * mw;
             {   // the other buffer becomes the syndrome again (its last readers passed barrier A)
@@ -649,13 +662,13 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const int base = P.col_base[DD] + i;                                       \
                         int o[DD];                                                                 \
                         double r[DD];                                                              \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = vpos_t[base + j * cnt]; \
+                        _Pragma("unroll") for (int j = 0; j < DD; ++j) o[j] = vp[base + j * cnt];    \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) r[j] = Rload(o[j]);         \
                         double s = r[0];                                                           \
                         _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];               \
                         const double val = s + prior_t[P.col_off[DD] + i];                         \
                         if (!frozen && val < 0.0) {                                                \
-                            _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(P.vrow[base + j * cnt]); \
+                            _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(vr[base + j * cnt]); \
                         }                                                                          \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) q_update(o[j], val, r[j]);  \
                     }                                                                              \
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 const int32_t* pos; int deg;
                 const double val = long_column_value(i, pos, deg);
                 if (!frozen && val < 0.0) {
-                    const int32_t* const row = P.vrow + (pos - vpos_t);
+                    const int32_t* const row = vr + (pos - vp);
                     for (int j = 0; j < deg; ++j) flip(row[j]);
                 }
                 for (int j = 0; j < deg; ++j) q_update(pos[j], val, Rload(pos[j]));

@@ -182,7 +182,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // phase, so the last iteration, which must settle before the registers are reused, keeps its second
     // barrier for the whole workgroup).  With early exit the next check step would be wasted work.
     constexpr bool ONE_BAR = ONE_BARRIER && FORCE_FULL && !MC;
-    extern __shared__ double smem[];
+    // dynamic LDS: the tables of the two elementary functions (qbp_math.hpp, NpImage) first -- a constant
+    // address, so that a table access is a row offset plus an immediate -- then the carve described above
+    extern __shared__ double smem_all[];
+    const double* const np_tab = smem_all;
+    double* const smem = smem_all + NP_LDS_DOUBLES;
     const int tid = threadIdx.x;
     const int m = P.m;
     const int S = P.S;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             double prod;
 #pragma unroll
             for (int j = 0; j < DC; ++j) {
-                t[j] = tanh_half_msg<VARIANT>(q[j]);
+                t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);
                 prod = (j == 0) ? t[0] : prod * t[j];         // np.prod, ascending column
             }
             // t_safe = where(|t| < 1e-15, 1e-15, t) (:122).  |t| <= 1, so a row whose product is at least
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 double po = div_nr(prod, ts);
                 po = __hiloint2double(__double2hiint(po) ^ (int)(sb << 31),
                                       __double2loint(po));   // * syndrome_sign
-                double r = atanh2(clip_unit<VARIANT>(po));
+                double r = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
                 if (VARIANT == 1) r = r * P.alpha;
                 put(j, r);
             }
@@ -324,6 +328,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         }
     }
     if (lane_valid) wmask = P.tab_writer[c];
+    np_tables_to_lds(smem_all, tid, blockDim.x);
+    if (use_r0) __syncthreads();                    // (the table of first check steps uses them)
     if (use_r0 && lane_valid && slot == 0) {
         // (this lane wrote the priors it reads here; the table is published by the barrier before the loop)
         double qp[DC];
@@ -732,12 +738,17 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 // Device evaluation of the math functions (accuracy tests).
 __global__ void debug_math_kernel(int kind, const double* x, double* y, long long n)
 {
+    __shared__ double np_tab[NP_LDS_DOUBLES];
+    np_tables_to_lds(np_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double v = x[i];
     switch (kind) {
-        case 0: y[i] = tanh_half(v); break;
-        case 1: y[i] = atanh2(v); break;
+        case 0: y[i] = tanh_half_msg<0>(v, np_tab); break;        // the kernels' tanh(q / 2)
+        case 1: y[i] = atanh2_msg(v, np_tab); break;               // the kernels' 2 atanh(y)
+        case 4: y[i] = tanh_half(v); break;                        // round-1/2 forms (QBP_MATH_FAST builds)
+        case 5: y[i] = atanh2(v); break;
         case 2: y[i] = __builtin_amdgcn_rcp(v); break;          // raw v_rcp_f64 (seed accuracy)
         default: y[i] = div_nr(1.0, v); break;
     }

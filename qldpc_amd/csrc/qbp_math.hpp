@@ -24,6 +24,8 @@
 #include <cmath>
 #include <cstdint>
 
+#include "qbp_np_tables.hpp"
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define QBP_HD __device__ __forceinline__
 #define QBP_RCP(x) __builtin_amdgcn_rcp(x)
@@ -174,17 +176,198 @@ QBP_HD double atanh2(double y)
     return __builtin_copysign(res, y);
 }
 
+// ---------------------------------------------------------------------------------------------
+// numpy-exact forms (round 3).  The reference's np.tanh / np.arctanh are, on the AVX512 hosts its
+// golden vectors come from, two straight-line FMA kernels over small tables (numpy 2.2.6's vendored SVML:
+// qbp_np_tables.hpp, tools/extract_np_svml.py).  Restated here operation by operation, they return numpy's
+// BITS, so the posterior LLRs of the device equal the reference's bit for bit instead of within a drift
+// that any other 1-ulp implementation accumulates over the iterations.
+//   tanh:    16 intervals by exponent and top mantissa bit of |x| (0.1875, 0.25, 0.375 ... 16, 24),
+//            degree-16 polynomial in r = |x| - midpoint, Horner.  No division.
+//   arctanh: 0.5 (log(1 + a) - log(1 - a)); each log by R = round4(rcp14(.)), r = R x - 1 (fma),
+//            -log R from a 16-entry table, degree-8 polynomial in r; double-double style recombination.
+//            rcp14 is the AVX512 instruction VRCP14PD: rounded to 4 mantissa bits it is a step function of
+//            the operand's top 16 mantissa bits (16 thresholds, tabulated on the build host).
+// Tables live in LDS (NP_LDS_BYTES per workgroup), one row per tanh interval (18 doubles: 144 B stride,
+// conflict-free for any mix of intervals across a wavefront).
+struct NpImage {
+    uint64_t tanh_row[16][18];      // {midpoint, c0 .. c16}
+    uint64_t log_hl[16][2];         // {log(1 + j/16) high, low}
+    uint32_t rcp_lut[64];           // by the top 6 mantissa bits: see np_rcp14_hi
+};
+constexpr int NP_LDS_BYTES = (int)sizeof(NpImage);      // 2816
+constexpr int NP_LDS_DOUBLES = NP_LDS_BYTES / 8;
+
+constexpr NpImage np_make_image()
+{
+    NpImage im{};
+    for (int i = 0; i < 16; ++i) {
+        im.tanh_row[i][0] = NP_TANH_SHIFTER[i];
+        for (int k = 0; k < 17; ++k) im.tanh_row[i][1 + k] = NP_TANH_COEF[k][i];
+        im.log_hl[i][0] = NP_ATANH_LOG_HI[i];
+        im.log_hl[i][1] = NP_ATANH_LOG_LO[i];
+    }
+    // R_hi = 0x3ff00000 - (k << 16), k = number of thresholds <= m16 (the operand's top 16 mantissa bits).
+    // Bin b holds m16 in [b << 10, (b + 1) << 10): at most one threshold inside.  The entry is
+    //   0x3ff0ffff - (k_left << 16) - (0x10000 - thr)      (thr = 0x10000 when the bin has none)
+    // so that (entry - m16) & 0xffff0000 is R_hi: m16 >= thr borrows exactly one unit of bit 16.
+    for (int b = 0; b < 64; ++b) {
+        uint32_t k_left = 0, thr = 0x10000u;
+        for (int j = 0; j < 16; ++j) {
+            if (NP_RCP14_THR16[j] <= (uint32_t)(b << 10)) ++k_left;
+            else if (NP_RCP14_THR16[j] < (uint32_t)((b + 1) << 10)) thr = NP_RCP14_THR16[j];
+        }
+        im.rcp_lut[b] = 0x3ff0ffffu - (k_left << 16) - (0x10000u - thr);
+    }
+    return im;
+}
+
+#if defined(__HIPCC__)
+static __device__ const NpImage g_np_image = np_make_image();
+// copy the tables into LDS (every thread of the workgroup calls this; the caller's barrier publishes)
+__device__ __forceinline__ void np_tables_to_lds(double* lds, int tid, int nthreads)
+{
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(&g_np_image);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(lds);
+    for (int i = tid; i < NP_LDS_DOUBLES; i += nthreads) dst[i] = src[i];
+}
+#endif
+
+QBP_HD unsigned np_hi(double x)
+{
+#ifdef QBP_DEVICE_BITS
+    return (unsigned)__double2hiint(x);
+#else
+    uint64_t u; __builtin_memcpy(&u, &x, 8); return (unsigned)(u >> 32);
+#endif
+}
+QBP_HD double np_from_hi_lo(unsigned hi, unsigned lo)
+{
+#ifdef QBP_DEVICE_BITS
+    return __hiloint2double((int)hi, (int)lo);
+#else
+    uint64_t u = ((uint64_t)hi << 32) | lo; double d; __builtin_memcpy(&d, &u, 8); return d;
+#endif
+}
+QBP_HD unsigned np_lo(double x)
+{
+#ifdef QBP_DEVICE_BITS
+    return (unsigned)__double2loint(x);
+#else
+    uint64_t u; __builtin_memcpy(&u, &x, 8); return (unsigned)u;
+#endif
+}
+
+// np.tanh(q * 0.5).  T: the NpImage in LDS (as doubles).  inf -> +-1; NaN -> +-1 here (the kernels' NaN-
+// preserving variant wraps it, tanh_half_msg).
+QBP_HD double np_tanh_half(double q, const double* T)
+{
+    const double x = q * 0.5;                                   // beliefPropagation.py:114
+    const unsigned hi = np_hi(x);
+    int e = (int)((hi >> 19) & 0xfffu);                         // exponent and top mantissa bit of |x|
+    e = e < 0x7f8 ? 0x7f8 : (e > 0x7f8 + 15 ? 0x7f8 + 15 : e);  // v_med3_i32
+    const double* row = T + (e - 0x7f8) * 18;
+    // (|x| >= 24 selects the constant row {0, 1, 0 ...}: the clamp only keeps 0 * inf out of it)
+    const double r = __builtin_fmin(__builtin_fabs(x), 32.0) - row[0];
+    double p = row[17];
+#pragma unroll
+    for (int k = 16; k >= 1; --k) p = __builtin_fma(p, r, row[k]);
+    return np_from_hi_lo(np_hi(p) | (hi & 0x80000000u), np_lo(p));
+}
+
+// hi dword of round4(rcp14(v)) for a positive normal v (its low dword is 0)
+QBP_HD unsigned np_rcp14_hi(unsigned v_hi, const unsigned* lut)
+{
+    const unsigned m16 = (v_hi >> 4) & 0xffffu;
+    const unsigned ent = lut[(v_hi >> 14) & 63u];
+    // mantissa part for v in [1, 2), then the operand's exponent: 2^-e
+    return (((ent - m16) & 0xffff0000u) + 0x3ff00000u) - (v_hi & 0x7ff00000u);
+}
+
+// 2.0 * np.arctanh(y), |y| < 1 (the caller clips to 0.9999999; NaN in -> NaN out)
+QBP_HD double np_arctanh_x2(double y, const double* T)
+{
+    const double* logt = T + 16 * 18;
+    const unsigned* lut = reinterpret_cast<const unsigned*>(T + 16 * 18 + 32);
+    const double a = __builtin_fabs(y);
+    const double P = a + 1.0, M = 1.0 - a;
+    const double Ph = P - 1.0, Mh = M - 1.0;
+    const double Pl = a - Ph;                       // 1 + a = P + Pl
+    const double Ml = a + Mh;                       // 1 - a = M - Ml
+    const unsigned rp_hi = np_rcp14_hi(np_hi(P), lut), rm_hi = np_rcp14_hi(np_hi(M), lut);
+    const double Rp = np_from_hi_lo(rp_hi, 0u), Rm = np_from_hi_lo(rm_hi, 0u);
+    double rp = __builtin_fma(Rp, P, -1.0);
+    rp = __builtin_fma(Pl, Rp, rp);
+    double rm = __builtin_fma(M, Rm, -1.0);
+    rm = __builtin_fma(-Ml, Rm, rm);
+    const double* lp = logt + ((rp_hi >> 16) & 15u) * 2;
+    const double* lm = logt + ((rm_hi >> 16) & 15u) * 2;
+    const double dE = (double)((int)(rm_hi >> 20) - (int)(rp_hi >> 20));     // VGETEXPPD difference
+    const double dHi = lm[0] - lp[0];
+    const double dLo = lm[1] - lp[1];
+    constexpr double C0 = __builtin_bit_cast(double, NP_ATANH_POLY[0]), C1 = __builtin_bit_cast(double, NP_ATANH_POLY[1]),
+                     C2 = __builtin_bit_cast(double, NP_ATANH_POLY[2]), C3 = __builtin_bit_cast(double, NP_ATANH_POLY[3]),
+                     C4 = __builtin_bit_cast(double, NP_ATANH_POLY[4]), C5 = __builtin_bit_cast(double, NP_ATANH_POLY[5]),
+                     C6 = __builtin_bit_cast(double, NP_ATANH_POLY[6]), C7 = __builtin_bit_cast(double, NP_ATANH_POLY[7]),
+                     C8 = __builtin_bit_cast(double, NP_ATANH_POLY[8]);
+    constexpr double LN2_HI = __builtin_bit_cast(double, NP_ATANH_LN2_HI), LN2_LO = __builtin_bit_cast(double, NP_ATANH_LN2_LO);
+    double pp = __builtin_fma(C0, rp, C1), pm = __builtin_fma(C0, rm, C1);
+    pp = __builtin_fma(rp, pp, C2); pm = __builtin_fma(rm, pm, C2);
+    pp = __builtin_fma(rp, pp, C3); pm = __builtin_fma(rm, pm, C3);
+    pp = __builtin_fma(rp, pp, C4); pm = __builtin_fma(rm, pm, C4);
+    pp = __builtin_fma(rp, pp, C5); pm = __builtin_fma(rm, pm, C5);
+    pp = __builtin_fma(rp, pp, C6); pm = __builtin_fma(rm, pm, C6);
+    pp = __builtin_fma(rp, pp, C7); pm = __builtin_fma(rm, pm, C7);
+    pp = __builtin_fma(rp, pp, C8); pm = __builtin_fma(rm, pm, C8);
+    const double Kh = __builtin_fma(LN2_HI, dE, dHi);
+    const double Kl = __builtin_fma(LN2_LO, dE, dLo);
+    const double rp2 = rp * rp, rm2 = rm * rm;
+    const double S1 = rp + Kh;
+    const double t4 = Kh - S1;
+    const double S2 = S1 - rm;
+    const double e1 = rp + t4;
+    const double t5 = S2 - S1;
+    const double A = __builtin_fma(rp2, pp, Kl);
+    const double B = __builtin_fma(-rm2, pm, e1);
+    const double e2 = rm + t5;
+    double s = A + B;
+    s = s - e2;
+    s = S2 + s;
+    // np.arctanh: s * (+-0.5); the caller's 2.0 * (beliefPropagation.py:126)
+    const double h = s * np_from_hi_lo(0x3fe00000u | (np_hi(y) & 0x80000000u), 0u);
+    return 2.0 * h;
+}
+
 // Variant-aware forms used by the kernels.  Plain sum-product (VARIANT 0) never produces a NaN
 // message from NaN-free priors (|R| is clipped, inf - finite = inf), so it keeps the two-instruction
 // min/max clip, which drops NaNs.  The damped variant (VARIANT 1, rework/decoding.py:131-191) can:
 // damping = 1 with an infinite prior gives Q = 1 * inf + 0 * inf = NaN (:179), and numpy then carries
 // the NaN through tanh, the row product, np.clip and arctanh into every message of that row.
+// QBP_MATH_FAST (build-time, A/B only): the round-1/2 functions above (2.3 / 1.2 ulp, not numpy's bits)
+#ifndef QBP_MATH_FAST
+#define QBP_MATH_FAST 0
+#endif
+// T: the NpImage in LDS
 template <int VARIANT>
-QBP_HD double tanh_half_msg(double q)
+QBP_HD double tanh_half_msg(double q, const double* T)
 {
+#if QBP_MATH_FAST
     const double t = tanh_half(q);
+#else
+    const double t = np_tanh_half(q, T);
+#endif
     if (VARIANT == 1) return q != q ? q : t;
     return t;
+}
+
+// 2 * arctanh(y) of a clipped message (beliefPropagation.py:126)
+QBP_HD double atanh2_msg(double y, const double* T)
+{
+#if QBP_MATH_FAST
+    return atanh2(y);
+#else
+    return np_arctanh_x2(y, T);
+#endif
 }
 
 template <int VARIANT>

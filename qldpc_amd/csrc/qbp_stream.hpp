@@ -73,7 +73,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
                                                    long long ES, long long Bc,
                                                    const int32_t* __restrict__ srow,
                                                    const int32_t* __restrict__ srow_e0, int begin,
-                                                   int end, double alpha)
+                                                   int end, double alpha, const double* np_tab)
 {
     double qn[D];
     {
@@ -121,7 +121,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
             double prod = 1.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                t[j] = tanh_half_msg<VARIANT>(q[j]);
+                t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);
                 prod = (j == 0) ? t[0] : prod * t[j];            // np.prod, ascending column
             }
 #pragma unroll
@@ -129,7 +129,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
                 const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
                 double po = div_nr(prod, ts);
                 po = sbit ? -po : po;
-                const double r = atanh2(clip_unit<VARIANT>(po));
+                const double r = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
                 R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
             }
         }
@@ -139,7 +139,8 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
 // Rows longer than STREAM_MAX_ROW_CLASS: plain two-pass form (R holds the tanh values in between).
 template <int VARIANT>
 __device__ __forceinline__ void stream_check_long(const double* Q, double* R, unsigned sbit,
-                                                  long long ES, int e0, int deg, double alpha)
+                                                  long long ES, int e0, int deg, double alpha,
+                                                  const double* np_tab)
 {
     if constexpr (VARIANT == 2) {
         double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
@@ -167,7 +168,7 @@ __device__ __forceinline__ void stream_check_long(const double* Q, double* R, un
     } else {
         double prod = 1.0;
         for (int j = 0; j < deg; ++j) {
-            const double t = tanh_half_msg<VARIANT>(Q[(long long)(e0 + j) * ES]);
+            const double t = tanh_half_msg<VARIANT>(Q[(long long)(e0 + j) * ES], np_tab);
             R[(long long)(e0 + j) * ES] = t;
             prod = (j == 0) ? t : prod * t;
         }
@@ -176,7 +177,7 @@ __device__ __forceinline__ void stream_check_long(const double* Q, double* R, un
             const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
             double po = div_nr(prod, ts);
             po = sbit ? -po : po;
-            const double r = atanh2(clip_unit<VARIANT>(po));
+            const double r = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
             R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
         }
     }
@@ -283,10 +284,14 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
                                                         const int32_t* __restrict__ g_svar,
                                                         const int32_t* __restrict__ g_sedge)
 {
+    // tables of tanh / arctanh (qbp_math.hpp): the kernel's only LDS use and its only barrier
+    __shared__ double np_tab[NP_LDS_DOUBLES];
+    np_tables_to_lds(np_tab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const long long lb = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long b = P.b0 + lb;
     const bool valid = lb < P.Bc && b < P.B;
-    if (!valid) return;                      // whole trailing lanes only: no barriers in this kernel
+    if (!valid) return;                      // whole trailing lanes only: no further barriers
     const int m = P.m, n = P.n;
     // Workspace layout [edge][syndrome]: neighbouring wavefronts touch neighbouring 512-byte lines,
     // which spreads every access wave over the HBM channels.  (A tile-major layout
@@ -311,13 +316,13 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
 #define QBP_ROW_CLASS(D)                                                                         \
         if (P.row_off[D + 1] > P.row_off[D])                                                     \
             stream_check_class<VARIANT, D>(Q, R, synT, ES, Bc, g_srow, g_srow_e0, P.row_off[D],  \
-                                           P.row_off[D + 1], P.alpha);
+                                           P.row_off[D + 1], P.alpha, np_tab);
         QBP_ROW_CLASS(1) QBP_ROW_CLASS(2) QBP_ROW_CLASS(3) QBP_ROW_CLASS(4)
         QBP_ROW_CLASS(5) QBP_ROW_CLASS(6) QBP_ROW_CLASS(7) QBP_ROW_CLASS(8)
 #undef QBP_ROW_CLASS
         for (int i = P.row_off[RC + 1]; i < P.row_off[RC + 2]; ++i)
             stream_check_long<VARIANT>(Q, R, synT[(long long)g_srow[i] * Bc], ES, g_srow_e0[i],
-                                       g_srow_deg[i], P.alpha);
+                                       g_srow_deg[i], P.alpha, np_tab);
 
         // ---- variable step -------------------------------------------------------------------
         if (!frozen)

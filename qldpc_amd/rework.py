@@ -15,7 +15,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
-from .bp import _check_iter, _prior, _syndromes, decode_one, decoder_for
+from .bp import _check_iter, _prior, _syndromes, decode_one, decoder_for, dense_colsum_flags
 from .osd import performOSD_enhanced  # noqa: F401  (rework/decoding.py:193; rework/main.py:6 imports it)
 
 
@@ -31,7 +31,8 @@ def _dense_messages(H, syndrome, initialBelief, variant, alpha, damping, clip_ll
 
 
 def performBeliefPropagationFast(H, syndrome, initialBelief, maxIter=50):
-    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter, _lib.SUM_PRODUCT)
+    hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter, _lib.SUM_PRODUCT,
+                                     flags=dense_colsum_flags(H))
     return hard, conv, llr, it
 
 
@@ -42,7 +43,7 @@ def performMinSum_Symmetric(H, syndrome, initialBelief, maxIter=50, alpha=1.0, d
         return 0, 0, _dense_messages(H, syndrome, initialBelief, _lib.MIN_SUM, alpha, damping,
                                      clip_llr, 0), 0
     hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter, _lib.MIN_SUM, alpha,
-                                     damping, clip_llr)
+                                     damping, clip_llr, flags=dense_colsum_flags(H, damped=True))
     return hard, conv, llr, it
 
 
@@ -55,5 +56,5 @@ def performBeliefPropagation_Symmetric(H, syndrome, initialBelief, maxIter=50, a
         return 0, 0, _dense_messages(H, syndrome, initialBelief, _lib.DAMPED_SP, alpha, damping,
                                      clip_llr, 10), 0
     hard, conv, llr, it = decode_one(H, syndrome, initialBelief, maxIter, _lib.DAMPED_SP, alpha,
-                                     damping, clip_llr)
+                                     damping, clip_llr, flags=dense_colsum_flags(H, damped=True))
     return hard, conv, llr, it

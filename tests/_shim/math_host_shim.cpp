@@ -3,3 +3,15 @@
 extern "C" void shim_tanh_half(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = qbp::tanh_half(x[i]); }
 extern "C" void shim_atanh2(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = qbp::atanh2(x[i]); }
 extern "C" void shim_div(const double* a, const double* b, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = qbp::div_nr(a[i], b[i]); }
+// numpy-exact forms: the image the kernels keep in LDS, here in host memory
+static const qbp::NpImage g_host_image = qbp::np_make_image();
+extern "C" void shim_np_tanh_half(const double* x, double* y, long n)
+{
+    const double* T = reinterpret_cast<const double*>(&g_host_image);
+    for (long i = 0; i < n; ++i) y[i] = qbp::np_tanh_half(x[i], T);
+}
+extern "C" void shim_np_arctanh_x2(const double* x, double* y, long n)
+{
+    const double* T = reinterpret_cast<const double*>(&g_host_image);
+    for (long i = 0; i < n; ++i) y[i] = qbp::np_arctanh_x2(x[i], T);
+}
