@@ -146,10 +146,12 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
  *   QBP_MIN_SUM   rework/decoding.py:58-59   R_new / alpha at iteration 0
  *   QBP_DAMPED_SP rework/decoding.py:168-169 R (before scaling by alpha) at iteration 10
  * (QBP_SUM_PRODUCT: the plain update, i.e. alpha = damping = 1 and no LLR clip whatever is passed.)
+ * flags: the column-sum order bits (QBP_FLAG_PAIRWISE_COLSUM / _DENSE_F_COLSUM / _DENSE_F_COLSUM_ITER0) of the
+ * iterations before the dump; everything else is ignored.
  */
 int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
                        int32_t variant, double alpha, double damping, double clip_llr,
-                       int32_t iteration, double* messages);
+                       int32_t iteration, uint32_t flags, double* messages);
 
 /*
  * The two histograms behind the alpha fit of rework/Alvarado.py:10-66 (estimate_alpha_from_code), on
@@ -162,7 +164,7 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
  */
 int qbp_message_histograms(qbp_handle* h, const uint8_t* syndromes, const uint8_t* errors,
                            const double* prior, int64_t B, int32_t variant, double alpha,
-                           double damping, double clip_llr, int32_t iteration, int32_t bins,
+                           double damping, double clip_llr, int32_t iteration, uint32_t flags, int32_t bins,
                            double* edges, int64_t* hist0, int64_t* hist1);
 
 /*
@@ -248,8 +250,10 @@ enum {
 int qbp_set_option(qbp_handle* h, int32_t option, int64_t value);
 int64_t qbp_get_info(qbp_handle* h, int32_t what);
 
-/* Device evaluation of the kernels' FP64 elementary functions, for accuracy tests:
- * kind 0: tanh(x/2), 1: 2*atanh(x), 2: raw v_rcp_f64(x), 3: div_nr(1, x).  Host buffers. */
+/* Device evaluation of the kernels' FP64 elementary functions, for tests:
+ * kind 0: np.tanh(x * 0.5), 1: 2.0 * np.arctanh(x) as the kernels compute them (numpy's bits: qbp_math.hpp),
+ * 2: raw v_rcp_f64(x), 3: div_nr(1, x), 4 / 5: the round-1/2 forms of 0 / 1 (QBP_MATH_FAST builds).
+ * Host buffers. */
 int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int64_t count);
 
 const char* qbp_last_error(void);

@@ -79,11 +79,14 @@ def lib():
                                        C.c_int64, C.c_void_p]
         L.oracle_bp_check_messages.restype = C.c_int
         L.oracle_bp_check_messages.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [
-            C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p]
+            C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
         L.oracle_osd0.restype = C.c_int
         L.oracle_osd0.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 5
         L.oracle_np_pairwise_sum.restype = C.c_double
         L.oracle_np_pairwise_sum.argtypes = [C.c_void_p, C.c_int32]
+        for f in (L.oracle_np_tanh, L.oracle_np_arctanh):
+            f.restype = None
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.oracle_mc_threshold.restype = C.c_uint32
         L.oracle_mc_threshold.argtypes = [C.c_double]
         _LIB = L
@@ -213,7 +216,7 @@ def osd0(H, syndrome, llr, hard):
     return out
 
 
-def check_messages(H, syndromes, prior, variant, alpha=1.0, damping=1.0, clip_llr=20.0, iteration=0):
+def check_messages(H, syndromes, prior, variant, alpha=1.0, damping=1.0, clip_llr=20.0, iteration=0, flags=0):
     """Edge messages float64[B, E] (CSR order): the reference's alpha_estimation=True output."""
     row_ptr, col_idx, m, n = csr_of(H)
     syn = np.ascontiguousarray(np.atleast_2d(np.asarray(syndromes)).astype(np.uint8))
@@ -222,7 +225,7 @@ def check_messages(H, syndromes, prior, variant, alpha=1.0, damping=1.0, clip_ll
     rc = lib().oracle_bp_check_messages(m, n, row_ptr.ctypes.data, col_idx.ctypes.data,
                                         syn.ctypes.data, pr.ctypes.data, syn.shape[0], int(variant),
                                         float(alpha), float(damping), float(clip_llr),
-                                        int(iteration), out.ctypes.data)
+                                        int(iteration), int(flags), out.ctypes.data)
     if rc:
         raise ValueError(rc)
     return out

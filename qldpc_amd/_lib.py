@@ -57,9 +57,9 @@ SIGNATURES = {
     "qbp_mc_sample_errors": (C.c_int, [_VP, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                        C.c_int64, _VP]),
     "qbp_check_messages": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_double, C.c_double,
-                                     C.c_double, C.c_int32, _VP]),
+                                     C.c_double, C.c_int32, C.c_uint32, _VP]),
     "qbp_message_histograms": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int32, C.c_double, C.c_double,
-                                         C.c_double, C.c_int32, C.c_int32, _VP, _VP, _VP]),
+                                         C.c_double, C.c_int32, C.c_uint32, C.c_int32, _VP, _VP, _VP]),
     "qbp_osd0_batch": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP]),
     "qbp_osd0_batch_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP]),
     "qbp_set_option": (C.c_int, [_VP, C.c_int32, C.c_int64]),
@@ -240,8 +240,9 @@ class Decoder:
 
     @_locked
     def check_messages(self, syndromes, prior, variant, alpha=1.0, damping=1.0, clip_llr=20.0,
-                       iteration=0):
-        """Check->variable messages float64[B, E] (CSR edge order) after iteration `iteration`."""
+                       iteration=0, flags=0):
+        """Check->variable messages float64[B, E] (CSR edge order) after iteration `iteration`
+        (`flags`: column-sum order of the iterations before it)."""
         syn = np.ascontiguousarray(syndromes, np.uint8)
         pr = np.ascontiguousarray(prior, np.float64)
         if syn.ndim != 2 or syn.shape[1] != self.m or pr.shape != (self.n,):
@@ -249,12 +250,12 @@ class Decoder:
         out = np.empty((syn.shape[0], len(self.col_idx)), np.float64)
         _check(load().qbp_check_messages(self._h, syn.ctypes.data, pr.ctypes.data, syn.shape[0],
                                          int(variant), float(alpha), float(damping),
-                                         float(clip_llr), int(iteration), out.ctypes.data))
+                                         float(clip_llr), int(iteration), int(flags), out.ctypes.data))
         return out
 
     @_locked
     def message_histograms(self, syndromes, errors, prior, variant, alpha=1.0, damping=1.0,
-                           clip_llr=20.0, iteration=0, bins=50):
+                           clip_llr=20.0, iteration=0, bins=50, flags=0):
         """(edges float64[bins + 1], hist0 int64[bins], hist1 int64[bins]): the check->variable
         messages of `check_messages`, binned on the device by the true value of their bit."""
         syn = np.ascontiguousarray(syndromes, np.uint8)
@@ -267,7 +268,7 @@ class Decoder:
         h1 = np.empty(int(bins), np.int64)
         _check(load().qbp_message_histograms(self._h, syn.ctypes.data, err.ctypes.data, pr.ctypes.data,
                                              syn.shape[0], int(variant), float(alpha), float(damping),
-                                             float(clip_llr), int(iteration), int(bins), edges.ctypes.data,
+                                             float(clip_llr), int(iteration), int(flags), int(bins), edges.ctypes.data,
                                              h0.ctypes.data, h1.ctypes.data))
         return edges, h0, h1
 

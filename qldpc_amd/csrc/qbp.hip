@@ -1136,10 +1136,13 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
 
 int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
                        int32_t variant, double alpha, double damping, double clip_llr,
-                       int32_t iteration, double* messages)
+                       int32_t iteration, uint32_t flags, double* messages)
 {
     int rc = check_decode_args(h, B, iteration + 1, variant);
     if (rc) return rc;
+    int col_mode = 0;                    // (only the column-sum order bits of `flags` are honoured)
+    flags &= QBP_FLAG_DENSE_F_COLSUM | QBP_FLAG_DENSE_F_COLSUM_ITER0 | QBP_FLAG_PAIRWISE_COLSUM;
+    if (prior) { rc = resolve_column_order(h, flags, prior, &col_mode); if (rc) return rc; }
     if (variant == QBP_SUM_PRODUCT) {
         // plain sum-product = the damped update with alpha = damping = 1 and no LLR clip: the
         // caller's alpha / damping / clip_llr are ignored, as QBP_SUM_PRODUCT ignores them everywhere
@@ -1161,8 +1164,8 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
     // taken before R * alpha)
     const double div = variant == QBP_MIN_SUM ? alpha : 1.0;
     rc = generic_launch(h, h->d_syn.p, h->d_prior.p, B, iteration + 1, variant, alpha, damping, clip_llr,
-                        QBP_FLAG_FORCE_FULL /* no early exit before the dump iteration */, nullptr,
-                        nullptr, nullptr, nullptr, h->d_llr.p, iteration, div, s);
+                        flags | QBP_FLAG_FORCE_FULL /* no early exit before the dump iteration */, nullptr,
+                        nullptr, nullptr, nullptr, h->d_llr.p, iteration, div, s, nullptr, col_mode);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(messages, h->d_llr.p, b * (size_t)h->E * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1171,11 +1174,16 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
 
 int qbp_message_histograms(qbp_handle* h, const uint8_t* syndromes, const uint8_t* errors, const double* prior,
                            int64_t B, int32_t variant, double alpha, double damping, double clip_llr,
-                           int32_t iteration, int32_t bins, double* edges, int64_t* hist0, int64_t* hist1)
+                           int32_t iteration, uint32_t flags, int32_t bins, double* edges, int64_t* hist0,
+                           int64_t* hist1)
 try {
     int rc = check_decode_args(h, B, iteration + 1, variant);
     if (rc) return rc;
     if (!syndromes || !errors || !prior || !edges || !hist0 || !hist1) return fail(QBP_E_INVALID, "null pointer");
+    int col_mode = 0;                    // (only the column-sum order bits of `flags` are honoured)
+    flags &= QBP_FLAG_DENSE_F_COLSUM | QBP_FLAG_DENSE_F_COLSUM_ITER0 | QBP_FLAG_PAIRWISE_COLSUM;
+    rc = resolve_column_order(h, flags, prior, &col_mode);
+    if (rc) return rc;
     if (bins < 1 || bins > 4096) return fail(QBP_E_INVALID, "bins = %d out of range (1 .. 4096)", bins);
     if (B == 0 || h->E == 0) return fail(QBP_E_INVALID, "no messages to bin (B = %lld, E = %d)", (long long)B, h->E);
     if (variant == QBP_SUM_PRODUCT) { variant = QBP_DAMPED_SP; alpha = 1.0; damping = 1.0; clip_llr = __builtin_inf(); }
@@ -1192,7 +1200,8 @@ try {
     HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior, n * sizeof(double), hipMemcpyHostToDevice, s));
     const double div = variant == QBP_MIN_SUM ? alpha : 1.0;
     rc = generic_launch(h, h->d_syn.p, h->d_prior.p, B, iteration + 1, variant, alpha, damping, clip_llr,
-                        QBP_FLAG_FORCE_FULL, nullptr, nullptr, nullptr, nullptr, h->d_llr.p, iteration, div, s);
+                        flags | QBP_FLAG_FORCE_FULL, nullptr, nullptr, nullptr, nullptr, h->d_llr.p, iteration,
+                        div, s, nullptr, col_mode);
     if (rc) return rc;
     // range of all messages (rework/Alvarado.py:41-44: the two classes share one range)
     const int grid = (int)std::min<size_t>(1024, (b * E + 255) / 256);
@@ -1584,7 +1593,7 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
 
 int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int64_t count)
 {
-    if (!h || !x || !y || count < 0 || kind < 0 || kind > 3) return fail(QBP_E_INVALID, "bad arguments");
+    if (!h || !x || !y || count < 0 || kind < 0 || kind > 5) return fail(QBP_E_INVALID, "bad arguments");
     if (count == 0) return QBP_OK;
     DeviceScope on_device(h->device);
     HIP_TRY(on_device.err);

@@ -23,7 +23,7 @@ def _dense_messages(H, syndrome, initialBelief, variant, alpha, damping, clip_ll
     dec = decoder_for(H)
     syn = _syndromes(syndrome, dec.m, batch=False).astype(np.uint8)
     msgs = dec.check_messages(syn[None, :], _prior(initialBelief, dec.n), variant, alpha, damping,
-                              clip_llr, iteration)[0]
+                              clip_llr, iteration, flags=dense_colsum_flags(H, damped=True))[0]
     R = np.zeros((dec.m, dec.n))
     rows = np.repeat(np.arange(dec.m), np.diff(dec.row_ptr))
     R[rows, dec.col_idx] = msgs

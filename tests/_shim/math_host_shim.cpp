@@ -15,3 +15,7 @@ extern "C" void shim_np_arctanh_x2(const double* x, double* y, long n)
     const double* T = reinterpret_cast<const double*>(&g_host_image);
     for (long i = 0; i < n; ++i) y[i] = qbp::np_arctanh_x2(x[i], T);
 }
+extern "C" void shim_np_rcp14_hi(const unsigned* v_hi, unsigned* r_hi, long n)
+{
+    for (long i = 0; i < n; ++i) r_hi[i] = qbp::np_rcp14_hi(v_hi[i], g_host_image.rcp_lut);
+}

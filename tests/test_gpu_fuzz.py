@@ -6,13 +6,11 @@ or negative), variants, iteration
 limits, batch sizes and flags.  Bars:
 
 * the device kernels (automatic choice, general-H, streaming) return identical bits on EVERY input;
-* device == oracle in hard decision, converged flag and iteration on every syndrome the oracle
-  decodes within 15 iterations (and on all of them when the iteration limit is <= 7), except
-  syndromes whose trajectory the replay below flags as noise-driven (an exact cancellation whose
-  rounding residue decides a bit, or which the reference scales up by dividing by +1e-15,
-  beliefPropagation.py:122-123: there two tanh/arctanh implementations legitimately part ways,
-  DESIGN.md section 2);
-* OSD-0 and the Monte-Carlo counters: identical to the oracle pipeline.
+* device == oracle in EVERY output bit (hard decision, converged flag, iteration, posterior LLRs) on EVERY
+  syndrome, in both column-sum orders (round 3: oracle and device run numpy's own tanh / arctanh kernels;
+  rounds 1-2 had to set aside exact cancellations, whose rounding residue the reference scales by 1e15 at
+  beliefPropagation.py:122-123, and trajectories that run long without converging);
+* OSD-0 and the Monte-Carlo counters: identical to the oracle pipeline, no exceptions.
 
 The default run is short (part of ``pytest -m gpu``); ``QBP_FUZZ_CASES=2000 python -m pytest
 tests/test_gpu_fuzz.py -s`` is the long campaign (profiles/r01_fuzz.txt holds one).
@@ -64,55 +62,9 @@ def random_matrix(rng):
     return kind, (rng.random((m, n)) < 0.5).astype(np.int64)
 
 
-def noise_driven(H, syn, prior, max_iter, variant, alpha, damping, clip_llr):
-    """Replay of the sum-product trajectories: True where the outcome hangs on rounding residue --
-    (a) some message Q = value - R is an exact cancellation (|Q| < 1e-12 |R|): whether its tanh falls
-    below the reference's 1e-15 threshold, and is then scaled by 1e15, differs between implementations, or (b) some posterior value is an exact cancellation of
-    macroscopic terms (|value| < 1e-12 of their magnitude, e.g. a weight-2 check returning
-    2 atanh(tanh(prior / 2)) = -prior to a weight-1 variable with the same prior): its sign, i.e. the
-    hard-decision bit and the convergence test, is then last-ulp noise of tanh/arctanh."""
-    flags = np.zeros(len(syn), bool)
-    if variant == _lib.MIN_SUM:
-        return flags
-    rows, cols = np.nonzero(H)
-    if len(rows) == 0:
-        return flags
-    with np.errstate(all="ignore"):
-        for i, s in enumerate(syn):
-            sign = 1.0 - 2.0 * s[rows]
-            Q = prior[cols].astype(float)
-            R = np.zeros(len(rows))
-            for _ in range(max_iter):
-                # (a): Q = value - R cancelled to residue (exactly 0 here may be 1e-15 elsewhere)
-                if ((np.abs(Q) < 1e-12 * np.abs(R)) & (np.abs(R) > 1e-9)).any():
-                    flags[i] = True
-                    break
-                t = np.tanh(Q / 2)
-                prod = np.ones(H.shape[0])
-                np.multiply.at(prod, rows, t)
-                ts = np.where(np.abs(t) < 1e-15, 1e-15, t)
-                R = 2 * np.arctanh(np.clip(prod[rows] / ts * sign, -0.9999999, 0.9999999))
-                if variant == _lib.DAMPED_SP:
-                    R = R * alpha
-                tot = np.zeros(H.shape[1])
-                np.add.at(tot, cols, R)
-                val = tot + prior
-                mag = np.zeros(H.shape[1])
-                np.add.at(mag, cols, np.abs(R))
-                if ((np.abs(val) < 1e-12 * (mag + np.abs(prior))) & (mag > 1e-9)).any():   # (exactly 0 here may be +-1e-15 elsewhere)
-                    flags[i] = True
-                    break
-                Qn = val[cols] - R
-                Q = Qn if variant == _lib.SUM_PRODUCT else np.clip(damping * Qn + (1 - damping) * Q,
-                                                                   -clip_llr, clip_llr)
-                if np.array_equal(((val < 0).astype(np.int64) @ H.T) % 2, s):
-                    break
-    return flags
-
-
 def test_fuzz_decode_kernels_vs_oracle():
     rng = np.random.default_rng(int(os.environ.get("QBP_FUZZ_SEED", "20261004")))
-    stats = dict(cases=0, syndromes=0, noisy=0, chaotic=0, kinds={}, kernels={1: 0, 2: 0, 3: 0})
+    stats = dict(cases=0, syndromes=0, kinds={}, kernels={1: 0, 2: 0, 3: 0})
     for case in range(CASES):
         kind, H = random_matrix(rng)
         m, n = H.shape
@@ -165,25 +117,21 @@ def test_fuzz_decode_kernels_vs_oracle():
                 for x, y in zip(a, alt):
                     assert np.array_equal(x, y, equal_nan=True), f"general-H memory mode {mem} differs: {tag}"
 
-        o = oracle.decode_batch(H, syn, prior, max_iter, variant, threads=8, **kw)
-        same = (a[0] == o[0]).all(axis=1) & (a[1] == o[1]) & (a[2] == o[2])
-        # Compared strictly: syndromes the oracle decodes within 15 iterations, and everything when
-        # the iteration limit is small.  Trajectories that run long without converging amplify
-        # last-ulp differences chaotically; they are only counted.
-        strict = (o[1] & (o[2] <= 15)) | (max_iter <= 7)
-        if not same[strict].all():
-            noisy = noise_driven(H, syn, prior, max_iter, variant, **kw)
-            bad = ~same & ~noisy & strict
-            assert not bad.any(), f"{int(bad.sum())} syndromes differ from the oracle: {tag}"
-            stats["noisy"] += int((~same & strict).sum())
-        stats["chaotic"] += int((~same & ~strict).sum())
-        quick = same & a[1] & (a[2] <= 10)
-        fin = np.isfinite(o[3]) & quick[:, None]
-        err_abs = np.abs(np.where(fin, a[3], 0.0) - np.where(fin, o[3], 0.0))
-        tol = np.maximum(1e-5 * np.abs(np.where(fin, o[3], 0.0)), 1e-7)
-        if not (err_abs <= tol).all():
-            noisy = noise_driven(H, syn, prior, max_iter, variant, **kw)
-            assert (err_abs <= tol)[~noisy].all(), f"LLR error {err_abs.max():.3e}: {tag}"
+        # device == oracle in EVERY output bit -- hard decision, converged flag, iteration, LLR -- on every
+        # syndrome, however long it ran (round 3: both sides evaluate numpy's own tanh / arctanh kernels, so
+        # exact cancellations, the 1e15-scaled residues of beliefPropagation.py:122 and chaotic non-converging
+        # trajectories all come out the same; rounds 1-2 had to set those aside).  Half of the cases in the
+        # column order of a Fortran-ordered H, where the matrix allows it.
+        d_flags, o_flags = flags, (oracle.FLAG_FORCE_FULL if flags else 0)
+        if case % 2 and H.sum(0).max() <= 3:
+            d_flags |= _lib.FLAG_DENSE_F_COLSUM
+            o_flags |= oracle.FLAG_DENSE_F_COLSUM
+            a = dec.decode(syn, prior, max_iter, variant, flags=d_flags, **kw)
+            stats["f_order"] = stats.get("f_order", 0) + 1
+        o = oracle.decode_batch(H, syn, prior, max_iter, variant, flags=o_flags, threads=8, **kw)
+        for x, y, what in zip(a, o, ("hard decision", "converged flag", "iteration", "LLR")):
+            assert np.array_equal(x, y, equal_nan=True), f"{what} differs from the oracle: {tag}"
+        assert ((a[3].view(np.uint64) == o[3].view(np.uint64)) | np.isnan(o[3])).all(), f"LLR bits: {tag}"
         stats["cases"] += 1
         stats["syndromes"] += B
         stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
@@ -253,14 +201,8 @@ def test_fuzz_mc_counters_vs_oracle():
         assert used == (2 if general else 1)
         ref = oracle.mc_counters(H, Lx, distance, p, prior, t0, t0 + T, draws=draws, seed=seed,
                                  max_iter=30, variant=variant, osd=osd, **kw)
-        if not np.array_equal(np.asarray(got)[:len(ref)], np.asarray(ref)):
-            errors = oracle.mc_errors(n, p, draws, seed, t0, T)
-            syn = (errors.astype(np.int64) @ H.T % 2).astype(np.uint8)
-            noisy = noise_driven(H, syn, prior, 30, variant, kw.get("alpha", 1.0), kw.get("damping", 1.0),
-                                 kw.get("clip_llr", 20.0))
-            chaotic = ~oracle.decode_batch(H, syn, prior, 30, variant, **kw)[1]
-            assert noisy.any() or chaotic.any(), \
-                f"MC counters differ: case {case} {m}x{n} T={T} kernel={used} osd={osd} {got} vs {ref}"
+        assert np.array_equal(np.asarray(got)[:len(ref)], np.asarray(ref)), \
+            f"MC counters differ: case {case} {m}x{n} T={T} kernel={used} osd={osd} {got} vs {ref}"
         done[used] += T
         if (case + 1) % 100 == 0:
             print(f"  ... {case + 1} Monte-Carlo cases", flush=True)

@@ -1,6 +1,7 @@
-"""The wide golden set (tests/golden/wide.npz: 13 500 syndromes decoded by the real reference):
-how often does an independent implementation of tanh/atanh change a hard decision, a converged
-flag or an iteration index?  Oracle on CPU; device on GPU."""
+"""The wide golden set (tests/golden/wide.npz: 17 500 syndromes decoded by the real reference, 3 700 of
+them not converged after 50 iterations): hard decision, converged flag, iteration index and the sum of the
+posterior LLRs must be IDENTICAL on every syndrome (round 3: numpy's own tanh / arctanh kernels and numpy's
+column-sum order; rounds 1-2 allowed a tolerance on the LLRs).  Oracle on CPU; device on GPU."""
 import os
 
 import numpy as np
@@ -33,54 +34,40 @@ def check(tag, p, decode, who):
     bad_conv = int((c != conv).sum())
     bad_iter = int((it != iters).sum())
     bad_hard = int((h != hard).any(1).sum())
-    fast = conv & (iters <= 20)
-    rel = np.abs(llr.sum(1) - llr_sum) / np.maximum(np.abs(llr_sum), 1e-300)
+    # the fixture stores `values.sum()` per syndrome (numpy's pairwise sum of the n posteriors): the same
+    # call on bit-identical values gives the same bits
+    s = np.array([row.sum() for row in llr])
+    bad_llr = int((s != llr_sum).sum())
     print(f"{who} {tag} p={p}: {len(conv)} syndromes, {int(conv.sum())} converged; mismatches vs the "
-          f"reference: converged {bad_conv}, iteration {bad_iter}, hard decision {bad_hard}; "
-          f"LLR-sum rel err (converged within 20 it) {rel[fast].max():.1e}")
-    # Converged syndromes: everything must agree.  Non-converged ones ran 50 chaotic iterations:
-    # their final hard decision may differ in a few bits between ANY two implementations, so a
-    # small number of rows is tolerated there and reported (none observed so far).
-    assert bad_conv == 0 and bad_iter == 0
-    assert int(((h != hard).any(1) & conv).sum()) == 0
-    assert bad_hard <= max(2, int(0.005 * (~conv).sum()))
-    assert rel[fast].max() <= 1e-5
+          f"reference: converged {bad_conv}, iteration {bad_iter}, hard decision {bad_hard}, LLR sum {bad_llr}")
+    assert bad_conv == 0 and bad_iter == 0 and bad_hard == 0 and bad_llr == 0
 
 
 @pytest.mark.parametrize("tag,p", CASES)
 def test_oracle_wide(tag, p):
-    check(tag, p, lambda H, s, pr: oracle.decode_batch(H, s, pr, 50), "oracle")
+    check(tag, p, lambda H, s, pr: oracle.decode_batch(H, s, pr, 50, flags=oracle.colsum_flags("fast4", H)),
+          "oracle")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,p", CASES)
 def test_device_wide(tag, p):
     from qldpc_amd import bp
-    check(tag, p, lambda H, s, pr: bp.decoder_for(H).decode(s.astype(np.uint8), pr, 50), "device")
+    check(tag, p, lambda H, s, pr: bp.decoder_for(H).decode(s.astype(np.uint8), pr, 50,
+                                                            flags=bp.dense_colsum_flags(H)), "device")
 
 
-def check_variant(prefix, variant, kw, p, decode, who):
-    code, syn, hard, conv, iters, llr_sum = load(prefix, p)
-    prior = np.full(code.n, np.log((1 - p) / p))
-    h, c, it, llr = decode(code.Hx, syn, prior, variant, kw)
-    fast = conv & (iters <= 20)
-    rel = np.abs(llr.sum(1) - llr_sum) / np.maximum(np.abs(llr_sum), 1e-300)
-    bad = int((c != conv).sum()) + int((it != iters).sum()) + int((h != hard).any(1).sum())
-    print(f"{who} {prefix} p={p}: 1000 syndromes, {int(conv.sum())} converged, {bad} mismatches vs the "
-          f"reference, LLR-sum rel err {rel[fast].max():.1e}")
-    assert np.array_equal(c, conv) and np.array_equal(it, iters) and np.array_equal(h, hard)
-    assert rel[fast].max() <= (1e-12 if variant == 2 else 1e-5)     # min-sum has no transcendental
-
-
-@pytest.mark.parametrize("prefix,variant,kw,p", VARIANT_CASES)
-def test_oracle_wide_variants(prefix, variant, kw, p):
-    check_variant(prefix, variant, kw, p,
-                  lambda H, s, pr, v, k: oracle.decode_batch(H, s, pr, 50, v, **k), "oracle")
+@pytest.mark.parametrize("tag,variant,kw,p", VARIANT_CASES)
+def test_oracle_wide_variants(tag, variant, kw, p):
+    fn = "minsum" if variant == 2 else "sym"
+    check(tag, p, lambda H, s, pr: oracle.decode_batch(H, s, pr, 50, variant,
+                                                       flags=oracle.colsum_flags(fn, H), **kw), "oracle")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prefix,variant,kw,p", VARIANT_CASES)
-def test_device_wide_variants(prefix, variant, kw, p):
+@pytest.mark.parametrize("tag,variant,kw,p", VARIANT_CASES)
+def test_device_wide_variants(tag, variant, kw, p):
     from qldpc_amd import bp
-    check_variant(prefix, variant, kw, p,
-                  lambda H, s, pr, v, k: bp.decoder_for(H).decode(s.astype(np.uint8), pr, 50, v, **k), "device")
+    check(tag, p, lambda H, s, pr: bp.decoder_for(H).decode(
+        s.astype(np.uint8), pr, 50, variant, kw["alpha"], kw["damping"], kw["clip_llr"],
+        bp.dense_colsum_flags(H, damped=True)), "device")
