@@ -483,7 +483,7 @@ def test_module_functions_from_a_thread_pool():
     from concurrent.futures import ThreadPoolExecutor
     from qldpc_amd import osd
     code = codes.load_code("[[144, 12, 12]]")
-    H = code.Hx
+    H = np.ascontiguousarray(code.Hx)     # (C order: the single-syndrome form then sums like the batch form)
     rng = np.random.default_rng(77)
     prior = mc.prior_of(0.05, code.n)
     jobs = [((rng.random((400 + 37 * i, code.n)) < 0.05).astype(np.int64) @ H.T % 2) for i in range(8)]
