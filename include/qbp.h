@@ -205,6 +205,17 @@ int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t 
                       uint32_t flags, int64_t* d_counters, void* stream);
 
 /*
+ * The same pipeline -- syndrome = H e, BP, [OSD-0,] classification, all on the device -- on T GIVEN error
+ * patterns (errors [T][n] 0/1 bytes, host) instead of sampled ones.  This is how the reference-pinned fixture of
+ * the classification rule (tests/golden/classify.npz: trials sampled and classified by the reference's own
+ * paperResults_GPU.py:113-144) is fed through the product path.  With QBP_FLAG_OSD0 at most
+ * QBP_MC_OSD_MAX_TRIALS patterns per call.
+ */
+int qbp_mc_run_errors(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, const uint8_t* errors,
+                      int64_t T, const double* prior, int32_t max_iter, int32_t variant, double alpha,
+                      double damping, double clip_llr, uint32_t flags, int64_t counters[QBP_NUM_COUNTERS]);
+
+/*
  * OSD-0 post-processing of B decoder outputs: decoding/OSD.py:3-28 performOSD (= OSD_enhanced.py
  * with order 0), any matrix size.  syndromes [B][m], llr [B][n], hard [B][n] -> solution [B][n].  Columns are
  * ordered by ascending |llr|; equal values by ascending column index (np.argsort's order of
@@ -241,6 +252,9 @@ enum {
                                          (default: one barrier, two copies of the messages in LDS; A/B, tests) */
     QBP_OPT_OSD_BIG = 7,         /* 1 = OSD-0 through the workgroup-per-syndrome kernel (matrix in
                                     global memory) even where the one-wavefront kernel fits (tests) */
+    QBP_OPT_DEBUG_THROW = 99,    /* tests (null handle allowed): raise inside the entry point -- 1 std::bad_alloc
+                                    (-> QBP_E_NOMEM), 2 std::runtime_error, 3 a non-standard exception
+                                    (-> QBP_E_INVALID): no exception crosses the ABI */
     QBP_INFO_M = 100, QBP_INFO_N = 101, QBP_INFO_EDGES = 102, QBP_INFO_MAX_ROW_DEG = 103,
     QBP_INFO_MAX_COL_DEG = 104, QBP_INFO_KERNEL_KIND = 105, /* 1 on-chip, 2 general-H, 3 streaming */
     QBP_INFO_THREADS = 106, QBP_INFO_LDS_BYTES = 107, QBP_INFO_GRID = 108, QBP_INFO_NUM_CU = 109,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "qbp_mc_run_device": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                     C.c_uint64, C.c_int64, C.c_int64, _VP, C.c_int32, C.c_int32,
                                     C.c_double, C.c_double, C.c_double, C.c_uint32, _VP, _VP]),
+    "qbp_mc_run_errors": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int64, _VP, C.c_int32, C.c_int32,
+                                    C.c_double, C.c_double, C.c_double, C.c_uint32, _VP]),
     "qbp_mc_sample_errors": (C.c_int, [_VP, C.c_double, C.c_int32, C.c_uint64, C.c_int64,
                                        C.c_int64, _VP]),
     "qbp_check_messages": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int32, C.c_double, C.c_double,
@@ -228,6 +230,27 @@ class Decoder:
                                      pr.ctypes.data, int(max_iter), int(variant), float(alpha),
                                      float(damping), float(clip_llr), int(flags), counters.ctypes.data))
         return counters
+
+    @_locked
+    def mc_run_errors(self, Lx, distance, errors, prior, max_iter=50, variant=SUM_PRODUCT, alpha=1.0, damping=1.0,
+                      clip_llr=20.0, flags=0):
+        """Counters int64[12] of the device pipeline (syndrome = H e, BP, [OSD-0,] classification) on GIVEN
+        error patterns uint8[T, n] instead of sampled ones (qbp_mc_run_errors)."""
+        Lx = np.ascontiguousarray(Lx, np.uint8)
+        pr = np.ascontiguousarray(prior, np.float64)
+        err = np.ascontiguousarray(errors, np.uint8)
+        if Lx.ndim != 2 or Lx.shape[1] != self.n or pr.shape != (self.n,) or err.ndim != 2 or err.shape[1] != self.n:
+            raise ValueError("bad shapes")
+        total = np.zeros(NUM_COUNTERS, np.int64)
+        step = self.mc_osd_step() if (int(flags) & FLAG_OSD0) else max(len(err), 1)
+        for a in range(0, len(err), step):
+            part = np.zeros(NUM_COUNTERS, np.int64)
+            chunk = err[a:a + step]
+            _check(load().qbp_mc_run_errors(self._h, Lx.ctypes.data, Lx.shape[0], int(distance), chunk.ctypes.data,
+                                            len(chunk), pr.ctypes.data, int(max_iter), int(variant), float(alpha),
+                                            float(damping), float(clip_llr), int(flags), part.ctypes.data))
+            total += part
+        return total
 
     def mc_run_device(self, Lx, distance, p, d_prior, trial_begin, trial_end, d_counters, draws=1,
                       seed=0, max_iter=50, variant=SUM_PRODUCT, alpha=1.0, damping=1.0,

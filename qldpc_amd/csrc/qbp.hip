@@ -8,6 +8,7 @@
 #include <cstring>
 #include <exception>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -34,8 +35,8 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
-// No C++ exception crosses the C ABI: every entry point that can allocate host memory is a
-// function-try-block ending in QBP_ABI_CATCH.
+// No C++ exception crosses the C ABI: EVERY extern "C" entry point is a function-try-block ending in
+// QBP_ABI_CATCH (std::bad_alloc -> QBP_E_NOMEM: tests/test_host_cpu.py forces one).
 #define QBP_ABI_CATCH                                                                      \
     catch (const std::bad_alloc&) { return fail(QBP_E_NOMEM, "out of host memory"); }     \
     catch (const std::exception& ex) { return fail(QBP_E_INVALID, "internal error: %s", ex.what()); } \
@@ -321,7 +322,7 @@ int build_tables(const int32_t* row_ptr, const int32_t* col_idx, int m, int n, H
     }
     if (T.max_row <= DC_SMALL && T.max_col <= DV_SMALL) { T.dc = DC_SMALL; T.dv = DV_SMALL; }
     else { T.dc = DC_WIDE; T.dv = DV_WIDE; }
-    T.fused_ok = (m <= 1024) && T.max_row <= T.dc && T.max_col <= T.dv &&
+    T.fused_ok = (m <= qbp::FUSED_MAX_THREADS) && T.max_row <= T.dc && T.max_col <= T.dv &&
                  fused_lds_bytes(T.dc, m, n, 1) <= 160 * 1024;
     if (T.fused_ok) {
         const int DC = T.dc, DV = T.dv, zoff = DC * m;
@@ -436,7 +437,7 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced = false, bo
     if (S <= 0) {
         // 16 wavefronts per workgroup (4 per SIMD at the kernel's 128-VGPR budget) was the fastest
         // geometry measured (profiles/r01_tune.txt); small batches spread over the CUs instead.
-        S = std::max(1, 1024 / std::max(m, 1));
+        S = std::max(1, qbp::FUSED_MAX_THREADS / std::max(m, 1));
         // With early exit the slots of a workgroup are in different iterations, yet every one of them
         // waits at the workgroup's barriers for the slowest (a slot in its first iteration copies six
         // table entries, its neighbour evaluates six tanh / division / atanh chains): two workgroups
@@ -444,12 +445,12 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced = false, bo
         // while the other synchronises or writes results -- are 2 - 18 % faster on every early-exit
         // workload measured, although [[288,12,18]] then runs 6 syndromes per CU instead of 7
         // (profiles/r02_ab_work_chunk.txt, second part).  Not for the (8, 4) shape (m > 512).
-        if (!forced && !h->opt_early_exit_full_wg && 512 / std::max(m, 1) >= 1 && S >= 2)
-            S = 512 / m;
+        if (!forced && !h->opt_early_exit_full_wg && (qbp::FUSED_MAX_THREADS / 2) / std::max(m, 1) >= 1 && S >= 2)
+            S = (qbp::FUSED_MAX_THREADS / 2) / m;
         const long long spread = (B + h->num_cu - 1) / std::max(h->num_cu, 1);
         if (spread < S) S = (int)std::max<long long>(spread, 1);
     }
-    S = std::min(S, std::max(1, 1024 / std::max(m, 1)));
+    S = std::min(S, std::max(1, qbp::FUSED_MAX_THREADS / std::max(m, 1)));
     if ((long long)S > B) S = (int)std::max<long long>(B, 1);
     cfg->dc = h->dc;
     cfg->slot_stride = h->dc * m + 2;
@@ -462,7 +463,7 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced = false, bo
     cfg->one_barrier = two ? 1 : 0;
     h->last_one_barrier = cfg->one_barrier;
     cfg->S = S;
-    cfg->threads = std::min(1024, ((S * m + 63) / 64) * 64);
+    cfg->threads = std::min(qbp::FUSED_MAX_THREADS, ((S * m + 63) / 64) * 64);
     // early exit: the first check step's messages as an LDS table, when it fits beside S slots
     const bool r0 = !forced && !h->opt_no_r0_table && fused_lds_bytes(h->dc, m, h->n, S, false, true) <= 160 * 1024;
     cfg->r0_table = r0 ? 1 : 0;
@@ -475,7 +476,7 @@ int make_cfg(qbp_handle* h, long long B, LaunchCfg* cfg, bool forced = false, bo
         // two workgroups per CU are queued: with early exit the second round evens out the tail
         // (measured +10 % at p = 0.01, neutral when every syndrome runs max_iter iterations).
         const int waves = cfg->threads / 64;
-        const int resident = std::max(1, std::min(16 / std::max(waves, 1), (int)(160 * 1024 / lds)));
+        const int resident = std::max(1, std::min((qbp::FUSED_MAX_THREADS / 64) / std::max(waves, 1), (int)(160 * 1024 / lds)));
         per_cu = 2 * resident;
     }
     const long long want = (B + S - 1) / S;
@@ -942,7 +943,7 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
                             int64_t B, int32_t max_iter, int32_t variant, double alpha,
                             double damping, double clip_llr, uint32_t flags, uint8_t* d_hard,
                             uint8_t* d_converged, int32_t* d_iters, double* d_llr, void* stream)
-{
+try {
     int rc = check_decode_args(h, B, max_iter, variant);
     if (rc) return rc;
     if (B == 0) return QBP_OK;
@@ -992,12 +993,13 @@ int qbp_decode_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const dou
     HIP_TRY(qbp::launch_fused(false, variant, P, cfg, s));
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
                      int32_t max_iter, int32_t variant, double alpha, double damping,
                      double clip_llr, uint32_t flags, uint8_t* hard, uint8_t* converged,
                      int32_t* iters, double* llr)
-{
+try {
     int rc = check_decode_args(h, B, max_iter, variant);
     if (rc) return rc;
     if (B == 0) return QBP_OK;
@@ -1133,11 +1135,12 @@ int qbp_decode_batch(qbp_handle* h, const uint8_t* syndromes, const double* prio
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* prior, int64_t B,
                        int32_t variant, double alpha, double damping, double clip_llr,
                        int32_t iteration, uint32_t flags, double* messages)
-{
+try {
     int rc = check_decode_args(h, B, iteration + 1, variant);
     if (rc) return rc;
     int col_mode = 0;                    // (only the column-sum order bits of `flags` are honoured)
@@ -1171,6 +1174,7 @@ int qbp_check_messages(qbp_handle* h, const uint8_t* syndromes, const double* pr
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 int qbp_message_histograms(qbp_handle* h, const uint8_t* syndromes, const uint8_t* errors, const double* prior,
                            int64_t B, int32_t variant, double alpha, double damping, double clip_llr,
@@ -1334,7 +1338,7 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
 
 int qbp_osd0_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const double* d_llr,
                           const uint8_t* d_hard, int64_t B, uint8_t* d_solution, void* stream)
-{
+try {
     if (!h) return fail(QBP_E_INVALID, "null handle");
     if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0");
     if (B == 0) return QBP_OK;
@@ -1345,10 +1349,11 @@ int qbp_osd0_batch_device(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     O.count = B; O.syndromes = d_syndromes; O.llr = d_llr; O.hard = d_hard; O.solution = d_solution;
     return osd_launch(h, O, B, static_cast<hipStream_t>(stream));
 }
+QBP_ABI_CATCH
 
 int qbp_osd0_batch(qbp_handle* h, const uint8_t* syndromes, const double* llr, const uint8_t* hard,
                    int64_t B, uint8_t* solution)
-{
+try {
     if (!h) return fail(QBP_E_INVALID, "null handle");
     if (B < 0) return fail(QBP_E_INVALID, "B must be >= 0");
     if (B == 0) return QBP_OK;
@@ -1370,13 +1375,14 @@ int qbp_osd0_batch(qbp_handle* h, const uint8_t* syndromes, const double* llr, c
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
-int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t distance,
-                      double p, int32_t draws, uint64_t seed, int64_t trial_begin,
-                      int64_t trial_end, const double* d_prior, int32_t max_iter,
-                      int32_t variant, double alpha, double damping, double clip_llr,
-                      uint32_t flags, int64_t* d_counters, void* stream)
-try {
+static int mc_run_impl(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t distance,
+                       double p, int32_t draws, uint64_t seed, int64_t trial_begin,
+                       int64_t trial_end, const uint8_t* d_errors_in, const double* d_prior, int32_t max_iter,
+                       int32_t variant, double alpha, double damping, double clip_llr,
+                       uint32_t flags, int64_t* d_counters, void* stream)
+{
     const int64_t T = trial_end - trial_begin;
     int rc = check_decode_args(h, T, max_iter, variant);
     if (rc) return rc;
@@ -1423,6 +1429,7 @@ try {
         M.lx_cols = h->d_lx_cols.p; M.trial_begin = trial_begin; M.seed = seed;
         M.threshold = mc_threshold(p); M.draws = draws; M.half_distance = distance / 2;
         M.counters = reinterpret_cast<long long*>(d_counters);
+        M.errors_in = d_errors_in;
         if (osd) {
             M.fail_list = h->d_fail_list.p; M.fail_count = h->d_fail_count.p;
             M.fail_syn = h->d_fail_syn.p; M.fail_llr = h->d_fail_llr.p;
@@ -1444,6 +1451,7 @@ try {
     P.lx_cols = h->d_lx_cols.p; P.trial_begin = trial_begin; P.seed = seed;
     P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = distance / 2;
     P.counters = reinterpret_cast<long long*>(d_counters);
+    P.errors_in = d_errors_in;
     if (osd) {
         P.fail_list = h->d_fail_list.p; P.fail_count = h->d_fail_count.p;
         P.fail_syn = h->d_fail_syn.p; P.fail_llr = h->d_fail_llr.p;
@@ -1458,13 +1466,52 @@ try {
     }
     return QBP_OK;
 }
+
+int qbp_mc_run_device(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t distance,
+                      double p, int32_t draws, uint64_t seed, int64_t trial_begin,
+                      int64_t trial_end, const double* d_prior, int32_t max_iter,
+                      int32_t variant, double alpha, double damping, double clip_llr,
+                      uint32_t flags, int64_t* d_counters, void* stream)
+try {
+    return mc_run_impl(h, Lx_host, k, distance, p, draws, seed, trial_begin, trial_end, nullptr, d_prior, max_iter,
+                       variant, alpha, damping, clip_llr, flags, d_counters, stream);
+}
+QBP_ABI_CATCH
+
+int qbp_mc_run_errors(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, const uint8_t* errors,
+                      int64_t T, const double* prior, int32_t max_iter, int32_t variant, double alpha,
+                      double damping, double clip_llr, uint32_t flags, int64_t counters[QBP_NUM_COUNTERS])
+try {
+    if (!h) return fail(QBP_E_INVALID, "null handle");
+    if (!errors || !prior || !counters) return fail(QBP_E_INVALID, "null pointer");
+    if (T < 0) return fail(QBP_E_INVALID, "T must be >= 0");
+    for (int i = 0; i < QBP_NUM_COUNTERS; ++i) counters[i] = 0;
+    if (T == 0) return QBP_OK;
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
+    const size_t n = (size_t)h->n;
+    HIP_TRY(h->d_prior.reserve(n));
+    HIP_TRY(h->d_counters.reserve(QBP_NUM_COUNTERS));
+    HIP_TRY(h->d_hard.reserve((size_t)T * n));            // (scratch of the host-pointer entries: the errors)
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->d_prior.p, prior, n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_hard.p, errors, (size_t)T * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, QBP_NUM_COUNTERS * sizeof(long long), s));
+    // (p, draws, seed are unused with stored errors)
+    const int rc = mc_run_impl(h, Lx, k, distance, 0.0, 1, 0, 0, T, h->d_hard.p, h->d_prior.p, max_iter, variant,
+                               alpha, damping, clip_llr, flags, reinterpret_cast<int64_t*>(h->d_counters.p), s);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    HIP_TRY(hipMemcpyAsync(counters, h->d_counters.p, QBP_NUM_COUNTERS * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return QBP_OK;
+}
 QBP_ABI_CATCH
 
 int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, double p,
                int32_t draws, uint64_t seed, int64_t trial_begin, int64_t trial_end,
                const double* prior, int32_t max_iter, int32_t variant, double alpha,
                double damping, double clip_llr, uint32_t flags, int64_t counters[QBP_NUM_COUNTERS])
-{
+try {
     if (!h) return fail(QBP_E_INVALID, "null handle");
     if (!prior || !counters) return fail(QBP_E_INVALID, "null pointer");
     DeviceScope on_device(h->device);
@@ -1484,41 +1531,25 @@ int qbp_mc_run(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t distance, do
     for (int i = 0; i < qbp::NUM_COUNTERS; ++i) counters[i] += tmp[i];
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 int qbp_mc_sample_errors(qbp_handle* h, double p, int32_t draws, uint64_t seed,
                          int64_t trial_begin, int64_t T, uint8_t* errors)
 try {
-    int rc = check_decode_args(h, T, 1, 0, /*need_fused=*/true);
-    if (rc) return rc;
+    if (!h) return fail(QBP_E_INVALID, "null handle");
+    if (T < 0 || trial_begin < 0) return fail(QBP_E_INVALID, "T and trial_begin must be >= 0");
     if (!errors) return fail(QBP_E_INVALID, "errors is null");
     if (draws != 1 && draws != 2) return fail(QBP_E_INVALID, "draws must be 1 or 2");
+    if (!(p >= 0.0 && p <= 1.0)) return fail(QBP_E_INVALID, "p = %g out of [0, 1]", p);
     if (T == 0) return QBP_OK;
+    if (T > ((int64_t)1 << 31)) return fail(QBP_E_INVALID, "at most 2^31 trials per call");
     DeviceScope on_device(h->device);
     HIP_TRY(on_device.err);
     hipStream_t s = h->stream;
-    rc = mc_prepare(h, nullptr, 0, s);
-    if (rc) return rc;
     const size_t n = h->n;
+    // (the sampler does not depend on H: any matrix, whichever kernel decodes it)
     HIP_TRY(h->d_hard.reserve((size_t)T * n));
-    HIP_TRY(h->d_prior.reserve(n));
-    HIP_TRY(h->d_counters.reserve(qbp::NUM_COUNTERS));
-    {
-        const std::vector<double> prior(n, 1.0);        // a local: copied synchronously
-        HIP_TRY(hipMemcpy(h->d_prior.p, prior.data(), n * sizeof(double), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, qbp::NUM_COUNTERS * sizeof(long long), s));
-    LaunchCfg cfg;
-    rc = make_cfg(h, T, &cfg, false, true);
-    if (rc) return rc;
-    FusedParams P{};
-    fill_static(h, P, cfg);
-    P.prior = h->d_prior.p; P.B = T; P.max_iter = 1; P.flags = 0;
-    P.alpha = 1.0; P.damping = 1.0; P.clip_llr = 20.0;
-    P.lx_cols = h->d_lx_cols.p; P.trial_begin = trial_begin; P.seed = seed;
-    P.threshold = mc_threshold(p); P.draws = draws; P.half_distance = 0;
-    P.counters = h->d_counters.p; P.errors_out = h->d_hard.p;
-    HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(qbp::launch_fused(true, QBP_MIN_SUM, P, cfg, s));
+    HIP_TRY(qbp::launch_mc_sample(h->d_hard.p, h->n, T, trial_begin, draws, seed, mc_threshold(p), s));
     HIP_TRY(hipMemcpyAsync(errors, h->d_hard.p, (size_t)T * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
@@ -1526,11 +1557,17 @@ try {
 QBP_ABI_CATCH
 
 int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
-{
+try {
+    if (option == QBP_OPT_DEBUG_THROW) {          // tests: what an exception inside an entry point turns into
+        if (value == 1) throw std::bad_alloc();
+        if (value == 2) throw std::runtime_error("requested by QBP_OPT_DEBUG_THROW");
+        if (value == 3) throw 3;
+        return QBP_OK;
+    }
     if (!h) return fail(QBP_E_INVALID, "null handle");
     switch (option) {
         case QBP_OPT_SLOTS_PER_BLOCK:
-            if (value < 0 || value * h->m > 1024) return fail(QBP_E_INVALID, "slots*m must be <= 1024");
+            if (value < 0 || value * h->m > qbp::FUSED_MAX_THREADS) return fail(QBP_E_INVALID, "slots*m must be <= %d", qbp::FUSED_MAX_THREADS);
             h->opt_slots = (int)value; return QBP_OK;
         case QBP_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 32) return fail(QBP_E_INVALID, "blocks per CU out of range");
@@ -1567,9 +1604,10 @@ int qbp_set_option(qbp_handle* h, int32_t option, int64_t value)
         default: return fail(QBP_E_INVALID, "unknown option %d", option);
     }
 }
+QBP_ABI_CATCH
 
 int64_t qbp_get_info(qbp_handle* h, int32_t what)
-{
+try {
     if (!h) return -1;
     switch (what) {
         case QBP_INFO_M: return h->m;
@@ -1590,9 +1628,10 @@ int64_t qbp_get_info(qbp_handle* h, int32_t what)
         default: return -1;
     }
 }
+catch (...) { return -1; }
 
 int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int64_t count)
-{
+try {
     if (!h || !x || !y || count < 0 || kind < 0 || kind > 5) return fail(QBP_E_INVALID, "bad arguments");
     if (count == 0) return QBP_OK;
     DeviceScope on_device(h->device);
@@ -1606,5 +1645,6 @@ int qbp_debug_math(qbp_handle* h, int32_t kind, const double* x, double* y, int6
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;
 }
+QBP_ABI_CATCH
 
 }  // extern "C"

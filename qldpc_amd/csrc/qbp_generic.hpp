@@ -111,6 +111,7 @@ struct GenericParams {
     int half_distance;
     long long* counters;
     uint8_t* wsE;                       // [grid][n4] sampled error of the current trial
+    const uint8_t* errors_in;           // optional [B][n]: these errors instead of sampled ones (qbp_mc_run_errors)
     // Monte-Carlo + OSD: records of the trials BP did not converge on, indexed by the trial's
     // position in this launch (same convention as the on-chip kernel, qbp_kernels.hpp)
     long long* fail_list;               // null = classify the BP output directly
@@ -141,7 +142,7 @@ __host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool ld
 // (rework/decoding.py:168-169 returns R before the alpha scaling).
 template <int VARIANT, int D>
 __device__ __forceinline__ void generic_row_update(const double (&q)[D], double (&r)[D], unsigned sbit,
-                                                   double alpha, bool scale, const double* np_tab)
+                                                   double alpha, bool scale, NpT np_tab)
 {
     if constexpr (VARIANT == 2) {
         double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
@@ -186,9 +187,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const double ts = t[j];
-            double po = div_nr(prod, ts);
-            po = __hiloint2double(__double2hiint(po) ^ (int)(sbit << 31), __double2loint(po));   // * sign
-            const double x = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
+            const double x = check_message<VARIANT>(div_nr(prod, ts), sbit, np_tab);     // :123-126
             r[j] = (VARIANT == 1 && scale) ? x * alpha : x;
         }
     }
@@ -269,10 +268,11 @@ template <int VARIANT, bool MC, int MEM>
 __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
 {
     constexpr bool LDSMSG = MEM == GENERIC_MEM_LDS;
-    extern __shared__ double gsm_all[];
-    const double* const np_tab = gsm_all;
+    extern __shared__ __attribute__((aligned(16))) double gsm_all[];
+    constexpr NpT np_tab = 0u;          // = the LDS address of gsm_all (no static LDS in this kernel: checked below)
     double* const gsm = gsm_all + NP_LDS_DOUBLES;
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (lds_address(gsm_all) != np_tab) __builtin_trap();
     np_tables_to_lds(gsm_all, tid, nt);           // (published by the first barrier of the syndrome loop)
     const int lane = tid & 63;
     const int m = P.m, n = P.n, E = P.E;
@@ -387,7 +387,8 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             // (beliefPropagationGPU.py:195)
             for (int g = tid; g < n4; g += nt)
                 reinterpret_cast<unsigned*>(err)[g] =
-                    mc_error_quad((unsigned long long)(P.trial_begin + b), g, P.draws, P.seed, P.threshold);
+                    P.errors_in ? mc_stored_quad(P.errors_in + b * n, g, n)
+                                : mc_error_quad((unsigned long long)(P.trial_begin + b), g, P.draws, P.seed, P.threshold);
         }
         __syncthreads();      // (also: the previous syndrome's last readers of LDS are done)
         // ---- syndrome bits in sorted check order; parity buffer 0 := syndrome -------------------
@@ -613,9 +614,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                     } else {
                         const double t = Rload(lbase + k);
                         const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
-                        double po = div_nr(L[3 * i], ts);
-                        po = sbit ? -po : po;
-                        const double x = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
+                        const double x = check_message<VARIANT>(div_nr(L[3 * i], ts), sbit, np_tab);
                         Rstore(lbase + k, (VARIANT == 1 && scale) ? x * P.alpha : x);
                     }
                 }

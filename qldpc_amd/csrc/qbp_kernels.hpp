@@ -44,6 +44,12 @@
 #ifndef QBP_WIDE_PACK
 #define QBP_WIDE_PACK 0        // (8, 4) shape: two LDS offsets per register
 #endif
+#ifndef QBP_SMALL_HOLD_R
+#define QBP_SMALL_HOLD_R 1     // (6, 3) decode builds: as above
+#endif
+#ifndef QBP_SMALL_PACK
+#define QBP_SMALL_PACK 0
+#endif
 #ifndef QBP_MC_HOLD_R
 #define QBP_MC_HOLD_R 0        // Monte-Carlo builds: as above
 #endif
@@ -100,7 +106,7 @@ struct FusedParams {
     int draws;
     int half_distance;          // distance // 2
     long long* counters;        // [NUM_COUNTERS], atomically added
-    uint8_t* errors_out;        // optional [B][n] dump of sampled errors (tests)
+    const uint8_t* errors_in;   // optional [B][n]: decode and classify THESE errors instead of sampling
     // Monte-Carlo + OSD: records of the trials BP did not converge on (indexed by the trial's
     // position b in this launch), and the list of those positions
     long long* fail_list;       // null = classify BP output directly
@@ -124,6 +130,10 @@ __device__ __forceinline__ ColdArgs cold_args()
     return p;
 }
 #define COLD(field) (cold_args()->field)
+// Markers around arithmetic that does not run every iteration, for the static instruction count of
+// tools/valu_mix.py (no effect on the hardware beyond two one-cycle scalar no-ops inside that path).
+#define QBP_COLD_BEGIN() asm volatile("s_nop 9")
+#define QBP_COLD_END() asm volatile("s_nop 10")
 
 // Syndromes a slot leader fetches at once when its syndromes have taken avg4 / 4 iterations on average
 // (see "Work distribution" in the kernel).
@@ -184,8 +194,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     constexpr bool ONE_BAR = ONE_BARRIER && FORCE_FULL && !MC;
     // dynamic LDS: the tables of the two elementary functions (qbp_math.hpp, NpImage) first -- a constant
     // address, so that a table access is a row offset plus an immediate -- then the carve described above
-    extern __shared__ double smem_all[];
-    const double* const np_tab = smem_all;
+    extern __shared__ __attribute__((aligned(16))) double smem_all[];
+    constexpr NpT np_tab = 0u;          // = the LDS address of smem_all: this kernel has no static LDS (checked below)
     double* const smem = smem_all + NP_LDS_DOUBLES;
     const int tid = threadIdx.x;
     const int m = P.m;
@@ -268,33 +278,34 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             double t[DC];
             double prod;
 #pragma unroll
-            for (int j = 0; j < DC; ++j) {
-                t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);
-                prod = (j == 0) ? t[0] : prod * t[j];         // np.prod, ascending column
-            }
+            for (int j = 0; j < DC; ++j) t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);     // np.tanh(Q * 0.5), :114
+#pragma unroll
+            for (int j = 0; j < DC; ++j) prod = (j == 0) ? t[0] : prod * t[j];     // np.prod, ascending column
             // t_safe = where(|t| < 1e-15, 1e-15, t) (:122).  |t| <= 1, so a row whose product is at least
             // 1e-15 in magnitude has no such factor: one wave-uniform test on the product replaces the six
             // compares and twelve selects in all but degenerate rows (messages of magnitude 1e-15, or six
             // messages near 0.006 at once -- those take the selects)
             if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(prod) >= 1e-15)) != 0ull) {
-                // (rare path.  Its limit is read from the kernel-argument segment for one reason only: that
-                // is how tools/valu_mix.py tells code that does not run every iteration from code that does,
-                // and the instruction count that prices the kernel must not include these selects.)
-                const double lim = COLD(max_iter) >= 0 ? 1e-15 : 0.0;
+                // (rare path, bracketed for tools/valu_mix.py: the instruction count that prices the kernel must
+                // not include it)
+                QBP_COLD_BEGIN();
 #pragma unroll
-                for (int j = 0; j < DC; ++j) t[j] = __builtin_fabs(t[j]) < lim ? lim : t[j];
-            }
+                for (int j = 0; j < DC; ++j) {
+                    const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
+                    // (a zero or denormal product: quotients of any size, down to the subnormals)
+                    const double r = check_message<VARIANT, false>(div_nr(prod, ts), sb, np_tab);
+                    put(j, VARIANT == 1 ? r * P.alpha : r);
+                }
+                QBP_COLD_END();
+            } else {
 #pragma unroll
-            for (int j = 0; j < DC; ++j) {
-                const double ts = t[j];
-                // prod / ts, correctly rounded like numpy's division: |prod| <= 1 and
-                // 1e-15 <= |ts| <= 1, so no operand scaling is needed (div_nr's precondition)
-                double po = div_nr(prod, ts);
-                po = __hiloint2double(__double2hiint(po) ^ (int)(sb << 31),
-                                      __double2loint(po));   // * syndrome_sign
-                double r = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
-                if (VARIANT == 1) r = r * P.alpha;
-                put(j, r);
+                for (int j = 0; j < DC; ++j) {
+                    // prod / t, correctly rounded like numpy's division: 1e-15 <= |prod| <= 1 and
+                    // 1e-15 <= |t| <= 1, so no operand scaling is needed (div_nr's precondition) and the
+                    // quotient is at least 1e-15 in magnitude (check_message: NORMAL)
+                    const double r = check_message<VARIANT, true>(div_nr(prod, t[j]), sb, np_tab);     // :123-126
+                    put(j, VARIANT == 1 ? r * P.alpha : r);
+                }
             }
         }
     };
@@ -303,7 +314,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // LDS word offsets of the columns of this check's variables.  The (6, 3) shape keeps one register
     // per offset; the (8, 4) shape and the Monte-Carlo builds pack two 16-bit offsets per register
     // (half the registers, one extra shift/mask per gather) -- their register budget is what limits them.
-    constexpr bool PACK_NBR = (DC > 6 && QBP_WIDE_PACK != 0) || (MC && QBP_MC_PACK != 0);
+    constexpr bool PACK_NBR = (DC > 6 && QBP_WIDE_PACK != 0) || (MC && QBP_MC_PACK != 0) ||
+                              (DC <= 6 && !MC && QBP_SMALL_PACK != 0);
     constexpr int NBR_W = PACK_NBR ? (DV + 1) / 2 : DV;
     unsigned nbr[DC][NBR_W];
     unsigned wmask = 0;
@@ -328,6 +340,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
         }
     }
     if (lane_valid) wmask = P.tab_writer[c];
+    if (lds_address(smem_all) != np_tab) __builtin_trap();
     np_tables_to_lds(smem_all, tid, blockDim.x);
     if (use_r0) __syncthreads();                    // (the table of first check steps uses them)
     if (use_r0 && lane_valid && slot == 0) {
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
     // Monte-Carlo builds are 6.6 % faster re-reading (their hot loop then runs without scratch
     // accesses); the (8, 4) shape is 4 % faster holding them, although that build spills 19
     // registers and the re-reading one none -- its iteration is not bound by those reloads.
-    constexpr bool HOLD_R = MC ? (QBP_MC_HOLD_R != 0 && DC <= 6) : (DC <= 6 || QBP_WIDE_HOLD_R != 0);
+    constexpr bool HOLD_R = MC ? (QBP_MC_HOLD_R != 0 && DC <= 6) : (DC <= 6 ? QBP_SMALL_HOLD_R != 0 : QBP_WIDE_HOLD_R != 0);
 
     // ---- per-syndrome state ---------------------------------------------------------------
     double Q[DC];
@@ -485,9 +498,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                 err_par ^= 1u;
                 unsigned* const err_words = reinterpret_cast<unsigned*>(err_buf());
                 const unsigned long long trial = (unsigned long long)(COLD(trial_begin) + b);
+                const uint8_t* const ein = COLD(errors_in);
                 for (int g = c; g < P.n_words4; g += m)
-                    err_words[g] =
-                        mc_error_quad(trial, g, COLD(draws), COLD(seed), COLD(threshold));
+                    err_words[g] = ein ? mc_stored_quad(ein + b * COLD(n), g, COLD(n))
+                                       : mc_error_quad(trial, g, COLD(draws), COLD(seed), COLD(threshold));
             }
             __syncthreads();                                      // B0
         }
@@ -646,7 +660,6 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     int ew = 0;
                     unsigned df = 0;
                     const unsigned long long* const lx = ca->lx_cols;
-                    uint8_t* const e_out = ca->errors_out;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         if ((wmask >> j) & 1u) {
@@ -656,7 +669,6 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                             df |= res;
                             const int v = var_lds[j * m + c];
                             if (res) lm ^= lx[v];
-                            if (e_out) e_out[row + v] = (uint8_t)e;
                         }
                     }
                     const unsigned char* const err_lds = err_buf();
@@ -667,7 +679,6 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                         ew += (int)e;
                         df |= res;
                         if (res) lm ^= lx[v];
-                        if (e_out) e_out[row + v] = (uint8_t)e;
                     }
                     if (lm) atomicXor(&mc_lmask[slot], lm);
                     if (ew) atomicAdd(&mc_weight[slot], ew);
@@ -738,8 +749,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
 // Device evaluation of the math functions (accuracy tests).
 __global__ void debug_math_kernel(int kind, const double* x, double* y, long long n)
 {
-    __shared__ double np_tab[NP_LDS_DOUBLES];
-    np_tables_to_lds(np_tab, threadIdx.x, blockDim.x);
+    __shared__ __attribute__((aligned(16))) double np_lds[NP_LDS_DOUBLES];
+    np_tables_to_lds(np_lds, threadIdx.x, blockDim.x);
+    const NpT np_tab = lds_address(np_lds);
     __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -752,6 +764,22 @@ __global__ void debug_math_kernel(int kind, const double* x, double* y, long lon
         case 2: y[i] = __builtin_amdgcn_rcp(v); break;          // raw v_rcp_f64 (seed accuracy)
         default: y[i] = div_nr(1.0, v); break;
     }
+}
+
+// The Monte-Carlo sampler on its own (qbp_mc_sample_errors): errors [T][n] of trials trial_begin .. + T, one
+// Philox evaluation per four qubits -- the bytes every Monte-Carlo kernel draws for itself (mc_error_quad).
+__global__ void mc_sample_kernel(uint8_t* errors, int n, long long T, long long trial_begin, int draws,
+                                 unsigned long long seed, unsigned threshold)
+{
+    const int n4 = (n + 3) / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * n4) return;
+    const long long b = i / n4;
+    const int g = (int)(i - b * n4);
+    const unsigned q = mc_error_quad((unsigned long long)(trial_begin + b), g, draws, seed, threshold);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (4 * g + k < n) errors[b * n + 4 * g + k] = (uint8_t)((q >> (8 * k)) & 1u);
 }
 
 #endif  // QBP_DEFINE_KERNELS

@@ -19,6 +19,12 @@ struct OsdBigWorkspace;
 // (row weight, column weight) shapes the on-chip kernel is instantiated for: every code of the
 // reference's codes/ is (6, 3); (8, 4) covers their space-time matrices (spaceTime.py: row weight
 // 6 + 2, column weight 3).  Anything wider, or with m > 1024, goes to the general-H kernel.
+// Threads per workgroup of the on-chip kernel = its register budget: 1024 threads are 4 wavefronts per SIMD
+// at <= 128 registers, 768 are 3 at <= 168 (build-time, A/B: tools/build_variants.sh).
+#ifndef QBP_FUSED_MAX_THREADS
+#define QBP_FUSED_MAX_THREADS 1024
+#endif
+constexpr int FUSED_MAX_THREADS = QBP_FUSED_MAX_THREADS;
 constexpr int DC_SMALL = 6, DV_SMALL = 3;
 constexpr int DC_WIDE = 8, DV_WIDE = 4;
 
@@ -31,6 +37,8 @@ struct LaunchCfg {
 // qbp_tu_fused.hip
 hipError_t launch_fused(bool mc, int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s);
 hipError_t launch_debug_math(int kind, const double* x, double* y, long long count, hipStream_t s);
+hipError_t launch_mc_sample(uint8_t* errors, int n, long long T, long long trial_begin, int draws,
+                            unsigned long long seed, unsigned threshold, hipStream_t s);
 // qbp_tu_generic.hip
 hipError_t launch_generic(bool mc, int mem, int variant, const GenericParams& G, int grid, int threads,
                           size_t lds, hipStream_t s);

@@ -191,11 +191,12 @@ QBP_HD double atanh2(double y)
 // Tables live in LDS (NP_LDS_BYTES per workgroup), one row per tanh interval (18 doubles: 144 B stride,
 // conflict-free for any mix of intervals across a wavefront).
 struct NpImage {
-    uint64_t tanh_row[16][18];      // {midpoint, c0 .. c16}
+    uint64_t tanh_row[16][18];      // {midpoint, c16, c15 .. c0}: Horner order, nine 16-byte pairs
     uint64_t log_hl[16][2];         // {log(1 + j/16) high, low}
-    uint32_t rcp_lut[64];           // by the top 6 mantissa bits: see np_rcp14_hi
+    uint32_t rcp_lut[64];           // by the top 6 mantissa bits: see np_make_image, np_rcp14_hi
+    uint32_t rcp_lut_p[64];         // the same + 0x03ff0000: for operands in [1, 2) taken as hi >> 4 (np_rcp14_hi_12)
 };
-constexpr int NP_LDS_BYTES = (int)sizeof(NpImage);      // 2816
+constexpr int NP_LDS_BYTES = (int)sizeof(NpImage);      // 3072
 constexpr int NP_LDS_DOUBLES = NP_LDS_BYTES / 8;
 
 constexpr NpImage np_make_image()
@@ -203,21 +204,24 @@ constexpr NpImage np_make_image()
     NpImage im{};
     for (int i = 0; i < 16; ++i) {
         im.tanh_row[i][0] = NP_TANH_SHIFTER[i];
-        for (int k = 0; k < 17; ++k) im.tanh_row[i][1 + k] = NP_TANH_COEF[k][i];
+        for (int k = 0; k < 17; ++k) im.tanh_row[i][17 - k] = NP_TANH_COEF[k][i];
         im.log_hl[i][0] = NP_ATANH_LOG_HI[i];
         im.log_hl[i][1] = NP_ATANH_LOG_LO[i];
     }
     // R_hi = 0x3ff00000 - (k << 16), k = number of thresholds <= m16 (the operand's top 16 mantissa bits).
-    // Bin b holds m16 in [b << 10, (b + 1) << 10): at most one threshold inside.  The entry is
-    //   0x3ff0ffff - (k_left << 16) - (0x10000 - thr)      (thr = 0x10000 when the bin has none)
-    // so that (entry - m16) & 0xffff0000 is R_hi: m16 >= thr borrows exactly one unit of bit 16.
+    // Bin b holds m16 in [b << 10, (b + 1) << 10): at most one threshold inside.  With
+    //   ent = 0x3ff0ffff - (k_left << 16) - (0x10000 - thr)      (thr = 0x10000 when the bin has none)
+    // (ent - m16) & 0xffff0000 is R_hi: m16 >= thr borrows exactly one unit of bit 16.  The stored entries
+    // carry, on top, the constant their reader would add next (bits >= 20: no effect on the borrow).
     for (int b = 0; b < 64; ++b) {
         uint32_t k_left = 0, thr = 0x10000u;
         for (int j = 0; j < 16; ++j) {
             if (NP_RCP14_THR16[j] <= (uint32_t)(b << 10)) ++k_left;
             else if (NP_RCP14_THR16[j] < (uint32_t)((b + 1) << 10)) thr = NP_RCP14_THR16[j];
         }
-        im.rcp_lut[b] = 0x3ff0ffffu - (k_left << 16) - (0x10000u - thr);
+        const uint32_t ent = 0x3ff0ffffu - (k_left << 16) - (0x10000u - thr);
+        im.rcp_lut[b] = ent + 0x3ff00000u;          // (+ the exponent bias of the result: np_rcp14_hi)
+        im.rcp_lut_p[b] = ent + 0x03ff0000u;        // (+ the operand's own exponent field >> 4: np_rcp14_hi_12)
     }
     return im;
 }
@@ -258,53 +262,122 @@ QBP_HD unsigned np_lo(double x)
 #endif
 }
 
+// A 16-byte pair of table entries: ONE ds_read_b128 (conflict-free for any mix of rows: the row stride of
+// 36 dwords visits every fourth of the 64 banks once in 16 rows).  Two 8-byte reads (ds_read2_b64) go through
+// 32 banks at half the rate, where rows i and i + 8 collide -- measured: every variant of the kernel then ran
+// at the same LDS-bound 5.0e6 syndromes/s.  T must be 16-byte aligned.
+struct alignas(16) NpPair { double a, b; };
+
+// Where the tables are.  On the device: the LDS BYTE ADDRESS of the NpImage as an integer -- every kernel keeps it
+// at a compile-time constant address (0: the start of the dynamic LDS of a kernel without static LDS, or the
+// address of a static array), so that a table access is `row offset + immediate`; through a pointer to the
+// dynamic-LDS symbol the compiler emits an add of the symbol's address -- zero -- per access.  Host build (tests):
+// a plain pointer.
+#if defined(QBP_DEVICE_BITS)
+typedef unsigned NpT;
+QBP_HD NpPair np_ld_pair(NpT t, unsigned byte_off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) NpPair*>(t + byte_off);
+}
+QBP_HD unsigned np_ld_u32(NpT t, unsigned byte_off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(t + byte_off);
+}
+#elif defined(__HIPCC__)      /* host pass of a device translation unit: same types, never executed */
+typedef unsigned NpT;
+QBP_HD NpPair np_ld_pair(NpT, unsigned) { return NpPair{0.0, 0.0}; }
+QBP_HD unsigned np_ld_u32(NpT, unsigned) { return 0u; }
+#else
+typedef const double* NpT;
+QBP_HD NpPair np_ld_pair(NpT t, unsigned byte_off)
+{
+    return *reinterpret_cast<const NpPair*>(reinterpret_cast<const char*>(t) + byte_off);
+}
+QBP_HD unsigned np_ld_u32(NpT t, unsigned byte_off)
+{
+    return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(t) + byte_off);
+}
+#endif
+#if defined(__HIPCC__)
+// LDS byte address of a pointer into shared memory
+__device__ __forceinline__ unsigned lds_address(const void* p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+#endif
+constexpr unsigned NP_OFF_LOG = 16 * 18 * 8, NP_OFF_LUT = NP_OFF_LOG + 256, NP_OFF_LUT_P = NP_OFF_LUT + 256;
+
 // np.tanh(q * 0.5).  T: the NpImage in LDS (as doubles).  inf -> +-1; NaN -> +-1 here (the kernels' NaN-
 // preserving variant wraps it, tanh_half_msg).
-QBP_HD double np_tanh_half(double q, const double* T)
+// Byte offset of the table row of |x| = q/2 from the high dword of x: the interval (0 .. 15) is the exponent
+// and top mantissa bit of |x| clamped to [0x7f8, 0x807] (v_bfe, v_med3); times 144 and minus the bias in ONE
+// 24-bit multiply-add.  Opaque on the device, so that the compiler keeps the offset in a register and
+// addresses the row's nine pairs as offset + immediate (it would otherwise re-associate the bias into every
+// access -- or, given an opaque interval, multiply with the quarter-rate v_mul_lo_u32).
+QBP_HD unsigned np_tanh_row(unsigned x_hi)
+{
+    int e = (int)((x_hi >> 19) & 0xfffu);
+    e = e < 0x7f8 ? 0x7f8 : (e > 0x7f8 + 15 ? 0x7f8 + 15 : e);
+#ifdef QBP_DEVICE_BITS
+    unsigned off = (unsigned)(__mul24(e, 144) - 0x7f8 * 144);
+    asm volatile("" : "+v"(off));
+    return off;
+#else
+    return (unsigned)(e - 0x7f8) * 144u;
+#endif
+}
+
+QBP_HD double np_tanh_half(double q, NpT T)
 {
     const double x = q * 0.5;                                   // beliefPropagation.py:114
-    const unsigned hi = np_hi(x);
-    int e = (int)((hi >> 19) & 0xfffu);                         // exponent and top mantissa bit of |x|
-    e = e < 0x7f8 ? 0x7f8 : (e > 0x7f8 + 15 ? 0x7f8 + 15 : e);  // v_med3_i32
-    const double* row = T + (e - 0x7f8) * 18;
-    // (|x| >= 24 selects the constant row {0, 1, 0 ...}: the clamp only keeps 0 * inf out of it)
-    const double r = __builtin_fmin(__builtin_fabs(x), 32.0) - row[0];
-    double p = row[17];
+    const unsigned row = np_tanh_row(np_hi(x));
+    NpPair c = np_ld_pair(T, row);                              // {midpoint, c16}
+    // (|x| >= 24 selects the constant row {0, 0 ... 0, 1}: the clamp only keeps 0 * inf out of it)
+    const double r = __builtin_fmin(__builtin_fabs(x), 32.0) - c.a;
+    double p = c.b;
 #pragma unroll
-    for (int k = 16; k >= 1; --k) p = __builtin_fma(p, r, row[k]);
-    return np_from_hi_lo(np_hi(p) | (hi & 0x80000000u), np_lo(p));
+    for (int s = 1; s <= 8; ++s) {
+        c = np_ld_pair(T, row + 16 * s);
+        p = __builtin_fma(p, r, c.a);
+        p = __builtin_fma(p, r, c.b);
+    }
+    return __builtin_copysign(p, x);                            // (p >= 0: the routine ORs the sign bit in)
 }
 
 // hi dword of round4(rcp14(v)) for a positive normal v (its low dword is 0)
-QBP_HD unsigned np_rcp14_hi(unsigned v_hi, const unsigned* lut)
+QBP_HD unsigned np_rcp14_hi(unsigned v_hi, NpT T)
 {
     const unsigned m16 = (v_hi >> 4) & 0xffffu;
-    const unsigned ent = lut[(v_hi >> 14) & 63u];
-    // mantissa part for v in [1, 2), then the operand's exponent: 2^-e
-    return (((ent - m16) & 0xffff0000u) + 0x3ff00000u) - (v_hi & 0x7ff00000u);
+    const unsigned ent = np_ld_u32(T, NP_OFF_LUT + ((v_hi >> 12) & 0xfcu));
+    // biased mantissa part (as for v in [1, 2): exponent field 0x3ff), then the operand's exponent: 2^-e
+    return ((ent - m16) & 0xffff0000u) - (v_hi & 0x7ff00000u);
 }
 
-// 2.0 * np.arctanh(y), |y| < 1 (the caller clips to 0.9999999; NaN in -> NaN out)
-QBP_HD double np_arctanh_x2(double y, const double* T)
+// the same for P in [1, 2) (P = 1 + a, a <= 0.9999999): the exponent term is a constant, folded into the
+// second table
+QBP_HD unsigned np_rcp14_hi_12(unsigned p_hi, NpT T)
 {
-    const double* logt = T + 16 * 18;
-    const unsigned* lut = reinterpret_cast<const unsigned*>(T + 16 * 18 + 32);
-    const double a = __builtin_fabs(y);
+    return (np_ld_u32(T, NP_OFF_LUT_P + ((p_hi >> 12) & 0xfcu)) - (p_hi >> 4)) & 0xffff0000u;
+}
+
+// 2.0 * np.arctanh(a) for 0 <= a <= 0.9999999 -- the magnitude; np.arctanh is odd in every bit (the routine
+// works on |y| and multiplies by +-0.5 at the end), so the kernels clip |y|, call this and set the sign bit.
+// NaN in -> NaN out.
+template <bool SCALE = true>
+QBP_HD double np_arctanh_x2_abs(double a, NpT T)
+{
     const double P = a + 1.0, M = 1.0 - a;
+    const unsigned rp_hi = np_rcp14_hi_12(np_hi(P), T), rm_hi = np_rcp14_hi(np_hi(M), T);
+    const NpPair lp = np_ld_pair(T, NP_OFF_LOG + ((rp_hi >> 12) & 0xf0u));
+    const NpPair lm = np_ld_pair(T, NP_OFF_LOG + ((rm_hi >> 12) & 0xf0u));
     const double Ph = P - 1.0, Mh = M - 1.0;
     const double Pl = a - Ph;                       // 1 + a = P + Pl
     const double Ml = a + Mh;                       // 1 - a = M - Ml
-    const unsigned rp_hi = np_rcp14_hi(np_hi(P), lut), rm_hi = np_rcp14_hi(np_hi(M), lut);
     const double Rp = np_from_hi_lo(rp_hi, 0u), Rm = np_from_hi_lo(rm_hi, 0u);
     double rp = __builtin_fma(Rp, P, -1.0);
     rp = __builtin_fma(Pl, Rp, rp);
     double rm = __builtin_fma(M, Rm, -1.0);
     rm = __builtin_fma(-Ml, Rm, rm);
-    const double* lp = logt + ((rp_hi >> 16) & 15u) * 2;
-    const double* lm = logt + ((rm_hi >> 16) & 15u) * 2;
-    const double dE = (double)((int)(rm_hi >> 20) - (int)(rp_hi >> 20));     // VGETEXPPD difference
-    const double dHi = lm[0] - lp[0];
-    const double dLo = lm[1] - lp[1];
     constexpr double C0 = __builtin_bit_cast(double, NP_ATANH_POLY[0]), C1 = __builtin_bit_cast(double, NP_ATANH_POLY[1]),
                      C2 = __builtin_bit_cast(double, NP_ATANH_POLY[2]), C3 = __builtin_bit_cast(double, NP_ATANH_POLY[3]),
                      C4 = __builtin_bit_cast(double, NP_ATANH_POLY[4]), C5 = __builtin_bit_cast(double, NP_ATANH_POLY[5]),
@@ -319,8 +392,9 @@ QBP_HD double np_arctanh_x2(double y, const double* T)
     pp = __builtin_fma(rp, pp, C6); pm = __builtin_fma(rm, pm, C6);
     pp = __builtin_fma(rp, pp, C7); pm = __builtin_fma(rm, pm, C7);
     pp = __builtin_fma(rp, pp, C8); pm = __builtin_fma(rm, pm, C8);
-    const double Kh = __builtin_fma(LN2_HI, dE, dHi);
-    const double Kl = __builtin_fma(LN2_LO, dE, dLo);
+    const double dE = (double)((int)(rm_hi >> 20) - (int)(rp_hi >> 20));     // VGETEXPPD difference
+    const double Kh = __builtin_fma(LN2_HI, dE, lm.a - lp.a);
+    const double Kl = __builtin_fma(LN2_LO, dE, lm.b - lp.b);
     const double rp2 = rp * rp, rm2 = rm * rm;
     const double S1 = rp + Kh;
     const double t4 = Kh - S1;
@@ -333,23 +407,25 @@ QBP_HD double np_arctanh_x2(double y, const double* T)
     double s = A + B;
     s = s - e2;
     s = S2 + s;
-    // np.arctanh: s * (+-0.5); the caller's 2.0 * (beliefPropagation.py:126)
-    const double h = s * np_from_hi_lo(0x3fe00000u | (np_hi(y) & 0x80000000u), 0u);
-    return 2.0 * h;
+    // np.arctanh's * 0.5, then the caller's 2.0 * (:126): the identity unless s * 0.5 is subnormal
+    // (|s| < 2^-1021, i.e. |a| of that size); callers that can rule that out skip the two multiplications
+    return SCALE ? 2.0 * (s * 0.5) : s;
 }
 
-// Variant-aware forms used by the kernels.  Plain sum-product (VARIANT 0) never produces a NaN
-// message from NaN-free priors (|R| is clipped, inf - finite = inf), so it keeps the two-instruction
-// min/max clip, which drops NaNs.  The damped variant (VARIANT 1, rework/decoding.py:131-191) can:
-// damping = 1 with an infinite prior gives Q = 1 * inf + 0 * inf = NaN (:179), and numpy then carries
-// the NaN through tanh, the row product, np.clip and arctanh into every message of that row.
+// 2.0 * np.arctanh(y), |y| <= 0.9999999 (NaN in -> NaN out)
+QBP_HD double np_arctanh_x2(double y, NpT T)
+{
+    const double t = np_arctanh_x2_abs(__builtin_fabs(y), T);
+    return np_from_hi_lo(np_hi(t) ^ (np_hi(y) & 0x80000000u), np_lo(t));       // * (+-0.5) * 2.0
+}
+
 // QBP_MATH_FAST (build-time, A/B only): the round-1/2 functions above (2.3 / 1.2 ulp, not numpy's bits)
 #ifndef QBP_MATH_FAST
 #define QBP_MATH_FAST 0
 #endif
 // T: the NpImage in LDS
 template <int VARIANT>
-QBP_HD double tanh_half_msg(double q, const double* T)
+QBP_HD double tanh_half_msg(double q, NpT T)
 {
 #if QBP_MATH_FAST
     const double t = tanh_half(q);
@@ -361,7 +437,7 @@ QBP_HD double tanh_half_msg(double q, const double* T)
 }
 
 // 2 * arctanh(y) of a clipped message (beliefPropagation.py:126)
-QBP_HD double atanh2_msg(double y, const double* T)
+QBP_HD double atanh2_msg(double y, NpT T)
 {
 #if QBP_MATH_FAST
     return atanh2(y);
@@ -379,6 +455,30 @@ QBP_HD double clip_unit(double x)
         return y > C ? C : y;
     }
     return __builtin_fmin(__builtin_fmax(x, -C), C);
+}
+
+// The tail of the check update for one edge (beliefPropagation.py:125-126):
+//     R = 2.0 * np.arctanh(np.clip(x * syndrome_sign, -0.9999999, 0.9999999)),   x = prod / t_safe.
+// Multiplying by +-1, clipping to a symmetric interval and np.arctanh (which works on |y| and multiplies by
+// +-0.5 at the end) are all odd functions bit for bit, so the magnitude goes through the clip and the
+// arctanh and the sign bit -- sign(x) XOR the syndrome bit -- is set at the end: one min and one bit-field
+// insert instead of a sign flip, a max, a min and the routine's own sign handling.
+// NORMAL: the caller guarantees |x| >= 2^-1000 or so (see np_arctanh_x2_abs)
+template <int VARIANT, bool NORMAL = false>
+QBP_HD double check_message(double x, unsigned sbit, NpT T)
+{
+#if QBP_MATH_FAST
+    const double xs = np_from_hi_lo(np_hi(x) ^ (sbit << 31), np_lo(x));
+    return atanh2(clip_unit<VARIANT>(xs));
+#else
+    constexpr double C = 0.9999999;                          // beliefPropagation.py:110
+    const double ax = __builtin_fabs(x);
+    double a;
+    if (VARIANT == 1) a = ax > C ? C : ax;                   // np.clip: a NaN stays a NaN
+    else a = __builtin_fmin(ax, C);
+    const double t = np_arctanh_x2_abs<!NORMAL>(a, T);
+    return np_from_hi_lo((np_hi(t) & 0x7fffffffu) | ((np_hi(x) ^ (sbit << 31)) & 0x80000000u), np_lo(t));
+#endif
 }
 
 }  // namespace qbp

@@ -37,6 +37,18 @@ __device__ __forceinline__ unsigned mc_error_quad(unsigned long long trial, int 
     return bytes;
 }
 
+// The same four bytes from a stored error pattern instead (errors [n] 0/1 bytes of one trial): the Monte-Carlo
+// kernels run on given errors when FusedParams / GenericParams::errors_in is set (qbp_mc_run_errors: the
+// reference-pinned classification test feeds the reference's own trials through the device pipeline).
+__device__ __forceinline__ unsigned mc_stored_quad(const uint8_t* errors, int g, int n)
+{
+    unsigned bytes = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (4 * g + i < n) bytes |= (unsigned)(errors[4 * g + i] & 1u) << (8 * i);
+    return bytes;
+}
+
 // Classification of one finished trial (paperResults_GPU.py:127-144 without the OSD call) into a
 // counter row: lm = logical mask of hard ^ error, ew = weight of the error, df = hard != error.
 __device__ __forceinline__ void mc_count_trial(int* cnt, unsigned long long lm, int ew, int df, int conv,

@@ -73,7 +73,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
                                                    long long ES, long long Bc,
                                                    const int32_t* __restrict__ srow,
                                                    const int32_t* __restrict__ srow_e0, int begin,
-                                                   int end, double alpha, const double* np_tab)
+                                                   int end, double alpha, NpT np_tab)
 {
     double qn[D];
     {
@@ -127,9 +127,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const double ts = __builtin_fabs(t[j]) < 1e-15 ? 1e-15 : t[j];
-                double po = div_nr(prod, ts);
-                po = sbit ? -po : po;
-                const double r = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
+                const double r = check_message<VARIANT>(div_nr(prod, ts), sbit, np_tab);
                 R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
             }
         }
@@ -140,7 +138,7 @@ __device__ __forceinline__ void stream_check_class(const double* Q, double* R, c
 template <int VARIANT>
 __device__ __forceinline__ void stream_check_long(const double* Q, double* R, unsigned sbit,
                                                   long long ES, int e0, int deg, double alpha,
-                                                  const double* np_tab)
+                                                  NpT np_tab)
 {
     if constexpr (VARIANT == 2) {
         double sprod = 1.0, min1 = __builtin_inf(), min2 = __builtin_inf();
@@ -175,9 +173,7 @@ __device__ __forceinline__ void stream_check_long(const double* Q, double* R, un
         for (int j = 0; j < deg; ++j) {
             const double t = R[(long long)(e0 + j) * ES];
             const double ts = __builtin_fabs(t) < 1e-15 ? 1e-15 : t;
-            double po = div_nr(prod, ts);
-            po = sbit ? -po : po;
-            const double r = atanh2_msg(clip_unit<VARIANT>(po), np_tab);
+            const double r = check_message<VARIANT>(div_nr(prod, ts), sbit, np_tab);
             R[(long long)(e0 + j) * ES] = (VARIANT == 1) ? r * alpha : r;
         }
     }
@@ -285,8 +281,9 @@ __global__ __launch_bounds__(256) void bp_stream_kernel(const StreamParams P,
                                                         const int32_t* __restrict__ g_sedge)
 {
     // tables of tanh / arctanh (qbp_math.hpp): the kernel's only LDS use and its only barrier
-    __shared__ double np_tab[NP_LDS_DOUBLES];
-    np_tables_to_lds(np_tab, threadIdx.x, blockDim.x);
+    __shared__ __attribute__((aligned(16))) double np_lds[NP_LDS_DOUBLES];
+    np_tables_to_lds(np_lds, threadIdx.x, blockDim.x);
+    const NpT np_tab = lds_address(np_lds);
     __syncthreads();
     const long long lb = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long b = P.b0 + lb;

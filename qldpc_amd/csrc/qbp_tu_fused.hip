@@ -49,9 +49,9 @@ hipError_t launch_variant(int variant, const FusedParams& P, const LaunchCfg& cf
     // __launch_bounds__(1024): 128-VGPR budget = 4 wavefronts per SIMD, the fastest geometry
     // measured (profiles/r01_tune.txt; builds with 3 or 5 waves per SIMD were slower).
     switch (variant) {
-        case QBP_SUM_PRODUCT: return launch_one<0, MC, 1024>(P, cfg, s);
-        case QBP_DAMPED_SP:   return launch_one<1, MC, 1024>(P, cfg, s);
-        default:              return launch_one<2, MC, 1024>(P, cfg, s);
+        case QBP_SUM_PRODUCT: return launch_one<0, MC, FUSED_MAX_THREADS>(P, cfg, s);
+        case QBP_DAMPED_SP:   return launch_one<1, MC, FUSED_MAX_THREADS>(P, cfg, s);
+        default:              return launch_one<2, MC, FUSED_MAX_THREADS>(P, cfg, s);
     }
 }
 
@@ -67,6 +67,16 @@ hipError_t launch_debug_math(int kind, const double* x, double* y, long long cou
     const int threads = 256;
     const long long blocks = (count + threads - 1) / threads;
     hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, kind, x, y, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_mc_sample(uint8_t* errors, int n, long long T, long long trial_begin, int draws,
+                            unsigned long long seed, unsigned threshold, hipStream_t s)
+{
+    const long long items = T * ((n + 3) / 4);
+    const int threads = 256;
+    hipLaunchKernelGGL(mc_sample_kernel, dim3((unsigned)((items + threads - 1) / threads)), dim3(threads), 0, s,
+                       errors, n, T, trial_begin, draws, seed, threshold);
     return hipGetLastError();
 }
 

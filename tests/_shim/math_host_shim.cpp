@@ -4,7 +4,7 @@ extern "C" void shim_tanh_half(const double* x, double* y, long n) { for (long i
 extern "C" void shim_atanh2(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = qbp::atanh2(x[i]); }
 extern "C" void shim_div(const double* a, const double* b, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = qbp::div_nr(a[i], b[i]); }
 // numpy-exact forms: the image the kernels keep in LDS, here in host memory
-static const qbp::NpImage g_host_image = qbp::np_make_image();
+alignas(16) static const qbp::NpImage g_host_image = qbp::np_make_image();
 extern "C" void shim_np_tanh_half(const double* x, double* y, long n)
 {
     const double* T = reinterpret_cast<const double*>(&g_host_image);
@@ -17,5 +17,12 @@ extern "C" void shim_np_arctanh_x2(const double* x, double* y, long n)
 }
 extern "C" void shim_np_rcp14_hi(const unsigned* v_hi, unsigned* r_hi, long n)
 {
-    for (long i = 0; i < n; ++i) r_hi[i] = qbp::np_rcp14_hi(v_hi[i], g_host_image.rcp_lut);
+    for (long i = 0; i < n; ++i) r_hi[i] = qbp::np_rcp14_hi(v_hi[i], reinterpret_cast<const double*>(&g_host_image));
+}
+// the kernels' tail of the check update: 2 arctanh(clip(x * sign)) with the sign bit set at the end
+extern "C" void shim_check_message(const double* x, const unsigned char* sbit, double* y, long n, int variant)
+{
+    const double* T = reinterpret_cast<const double*>(&g_host_image);
+    for (long i = 0; i < n; ++i)
+        y[i] = variant == 1 ? qbp::check_message<1>(x[i], sbit[i], T) : qbp::check_message<0>(x[i], sbit[i], T);
 }

@@ -49,6 +49,24 @@ def test_argument_validation_before_device(lib):
     assert lib.qbp_create(None, None, 1, 2, 0, C.byref(h)) == -1
 
 
+def test_no_exception_crosses_the_abi(lib):
+    """Every extern "C" entry point of qbp.hip is a function-try-block (checked in the source), and what the
+    catch clauses turn an exception into is observed through QBP_OPT_DEBUG_THROW, which raises inside one:
+    std::bad_alloc -> QBP_E_NOMEM, anything else -> QBP_E_INVALID; the process survives."""
+    src = open(os.path.join(ROOT, "qldpc_amd", "csrc", "qbp.hip")).read()
+    body = src[src.index('extern "C" {'):]
+    entries = re.findall(r"^(?:int|int64_t|void|const char\*) (qbp_\w+)\(([^)]*)\)\n(try )?\{", body, re.M)
+    trivial = {"qbp_last_error", "qbp_version", "qbp_destroy"}        # return a pointer / free: nothing to throw
+    for name, _, is_try in entries:
+        assert is_try or name in trivial, f"{name} is not a function-try-block"
+    assert {e[0] for e in entries if e[2]} >= set(_lib.SIGNATURES) - trivial
+    assert lib.qbp_set_option(None, 99, 1) == -5 and b"memory" in lib.qbp_last_error()       # QBP_E_NOMEM
+    assert lib.qbp_set_option(None, 99, 2) == -1 and b"QBP_OPT_DEBUG_THROW" in lib.qbp_last_error()
+    assert lib.qbp_set_option(None, 99, 3) == -1
+    assert lib.qbp_set_option(None, 99, 0) == 0
+    assert lib.qbp_set_option(None, 1, 0) == -1                        # (null handle otherwise)
+
+
 def test_csr_from_H_matches_scipy():
     from scipy.sparse import csr_matrix
     for name in ("steane", "[[72, 12, 6]]", "[[288, 12, 18]]"):

@@ -52,6 +52,45 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert 0 < s["ler"] < 1 and s["mean_iterations"] >= 1
 
 
+def _oracle_runner_osd(code, p, begin, end):
+    return oracle.mc_counters(code.Hx, code.Lx, code.distance, p, mc.prior_of(p, code.n), begin,
+                              end, draws=1, seed=5, max_iter=20, osd=True)
+
+
+def _worker8(rank, world, port, out, trials):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def all_reduce(table):
+        t = torch.from_numpy(table.copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    table = mc.run_sweep("[[72, 12, 6]]", [0.08, 0.05, 0.02], trials, rank=rank, world=world,
+                         runner=_oracle_runner_osd, all_reduce=all_reduce)
+    if rank == 0:
+        np.save(out, table)
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_ragged_with_osd_equal_one_rank(tmp_path):
+    """The layout of BASELINE configs 4 / 5 -- 8 ranks, BP + OSD-0, one all-reduce -- rehearsed over gloo with
+    a trial count that does not divide by 8 (shards of 37 and 38 trials) and one smaller than the world
+    size (some ranks own nothing): the reduced table equals the single-rank one, counter for counter."""
+    for trials in (301, 5):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"table8_{trials}.npy")
+        mp.spawn(_worker8, args=(8, port, out, trials), nprocs=8, join=True)
+        eight = np.load(out)
+        one = mc.run_sweep("[[72, 12, 6]]", [0.08, 0.05, 0.02], trials, runner=_oracle_runner_osd)
+        assert np.array_equal(one, eight)
+        assert (one[:, 0] == trials).all()
+        if trials > 100:
+            assert one[0, 6] > 0                     # some trials did go through OSD-0
+
+
 def test_shard_ranges_tile():
     for trials in (0, 1, 7, 1000, 125001):
         for world in (1, 2, 3, 8):

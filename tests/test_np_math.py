@@ -90,6 +90,31 @@ def test_against_live_numpy(impl):
     assert golden_util.same_bits(atanh_f(y), np.arctanh(y)).all()
 
 
+def test_check_message_is_the_references_expression():
+    """qbp_math.hpp: check_message -- clip the magnitude, arctanh of the magnitude, sign bit (sign of x XOR
+    syndrome bit) set at the end -- against the reference's own expression
+    2.0 * np.arctanh(np.clip(x * syndrome_sign, -0.9999999, 0.9999999)) evaluated by numpy's goldens' rule:
+    here through the oracle's np_arctanh, which the known-answer test pins to numpy."""
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.uniform(-1.5, 1.5, 200000), rng.normal(size=100000) * 1e-6, np.tanh(rng.normal(size=200000) * 4),
+                        rng.choice([-1, 1], 50000) * (1 - 10.0 ** rng.uniform(-9, 0, 50000)),
+                        np.array([0.0, -0.0, 1.0, -1.0, 0.9999999, -0.9999999, 1e-310, -1e-310, 5.0, -7.0, np.inf, -np.inf])])
+    sbit = rng.integers(0, 2, len(x)).astype(np.uint8)
+    want = 2.0 * _call(oracle.lib().oracle_np_arctanh, np.clip(x * (1.0 - 2.0 * sbit), -0.9999999, 0.9999999))
+    got = np.empty_like(x)
+    for variant in (0, 1):
+        xs, sb = x, sbit
+        if variant == 1:
+            xs = np.concatenate([x, [np.nan]]); sb = np.concatenate([sbit, [1]]).astype(np.uint8)
+            w = np.concatenate([want, [np.nan]])
+        else:
+            w = want
+        got = np.empty_like(xs)
+        _shim().shim_check_message(xs.ctypes.data_as(C.c_void_p), sb.ctypes.data_as(C.c_void_p),
+                                   got.ctypes.data_as(C.c_void_p), C.c_long(len(xs)), C.c_int(variant))
+        assert golden_util.same_bits(got, w).all(), variant
+
+
 def test_reciprocal_table_exhaustive():
     """Device LUT form (qbp_math.hpp: np_rcp14_hi) == the threshold count of the oracle (np_math.h:
     np_rcp14_r4), for every value of the 16 mantissa bits that matter, other mantissa bits random, exponents

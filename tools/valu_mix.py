@@ -14,9 +14,9 @@ loads, not from a committed profile:
 3. inside the loop, forward conditional branches delimit if-regions; a region is COLD when its own
    instructions (not those of nested regions) touch global memory or the kernel-argument segment --
    in these kernels that is exactly the once-per-syndrome work (loading a syndrome, emitting outputs,
-   drawing the next work item), which is skipped by its branch in all but one of max_iter iterations
-   (the kernels mark their one rarely taken arithmetic path -- the |t| < 1e-15 selects of the check step,
-   entered only when a row's product is below 1e-15 -- the same way: it reads a kernel argument);
+   drawing the next work item), which is skipped by its branch in all but one of max_iter iterations;
+   the kernels' one rarely taken ARITHMETIC path -- the |t| < 1e-15 form of the check step, entered only when
+   a row's product is below 1e-15 -- is bracketed by explicit markers instead (`s_nop 9` ... `s_nop 10`);
 4. every other vector-ALU instruction in the loop is counted, by class (the classes the in-run
    microbenchmark tools/ubench/valu_rates.hip measures issue rates for).
 
@@ -160,8 +160,25 @@ def loop_mix(insts):
             r = innermost(a)
             if r is not None:
                 cold_regions.add(r)
+    # explicit markers: the kernels bracket arithmetic that does not run every iteration (the |t| < 1e-15 path
+    # of the check step) with `s_nop 9` ... `s_nop 10` (qbp_kernels.hpp: QBP_COLD_BEGIN / QBP_COLD_END)
+    marks = sorted((a, o.strip()) for a, m, o, t in body if m == "s_nop" and o.strip() in ("9", "10"))
+    marked = []
+    open_at = None
+    for a, which in marks:
+        if which == "9":
+            if open_at is not None:
+                raise RuntimeError(f"cold marker at {open_at:#x} not closed before {a:#x}")
+            open_at = a
+        else:
+            if open_at is None:
+                raise RuntimeError(f"cold end marker at {a:#x} without a begin")
+            marked.append((open_at, a))
+            open_at = None
+    if open_at is not None:
+        raise RuntimeError(f"cold marker at {open_at:#x} not closed")
     def in_cold(addr):
-        return any(s < addr < e for s, e in cold_regions)
+        return any(s < addr < e for s, e in cold_regions) or any(s <= addr <= e for s, e in marked)
     mix = collections.Counter()
     other = collections.Counter()
     mnems = collections.Counter()
