@@ -76,16 +76,24 @@ def cpu_baseline(code, syndromes, prior, budget_s=12.0):
     dt = time.perf_counter() - t0
     out = {"value": nsamp / dt, "unit": "syndromes/s", "cores": 1, "kind": "port",
            "sample": f"first {nsamp} syndromes of the same batch, forced {MAX_ITER} iterations, "
-                     f"{dt:.1f} s on 1 of {os.cpu_count()} host cores (oracle/bp_oracle.c)"}
-    threads = max(1, min(16, os.cpu_count() or 1))      # a 1-GPU box's CPU share is 16 cores
-    if threads > 1:
-        nmt = int(min(len(syndromes), nsamp * min(threads, 8)))
+                     f"{dt:.1f} s on 1 of {os.cpu_count()} host cores (oracle/bp_oracle.c: numpy's own tanh / "
+                     "arctanh kernels restated in scalar C, the same bits as the reference)"}
+    host = host_cpu_info()
+    out["host"] = host
+    # OpenMP over syndromes (the decoder itself stays the scalar restatement): this job's share of the host (a
+    # 1-GPU box is given 16 cores' worth) and -- SURVEY 8(d)(ii) -- one worker per physical core this process may
+    # run on
+    for key, threads in (("multi_thread", max(1, min(16, host["usable_logical_cpus"]))),
+                         ("all_physical_cores", max(1, min(host["physical_cores"], host["usable_logical_cpus"])))):
+        if threads <= 1 or (key == "all_physical_cores" and threads == out.get("multi_thread", {}).get("cores")):
+            continue
+        nmt = int(min(len(syndromes), max(2 * threads, nsamp * min(threads, 8) // (2 if key == "all_physical_cores" else 1))))
         t0 = time.perf_counter()
         oracle.decode_batch(code.Hx, syndromes[:nmt], prior, MAX_ITER, flags=oracle.FLAG_FORCE_FULL,
                             threads=threads)
         dtm = time.perf_counter() - t0
-        out["multi_thread"] = {"value": nmt / dtm, "unit": "syndromes/s", "cores": threads,
-                               "sample": f"{nmt} syndromes, {dtm:.1f} s, OpenMP over syndromes"}
+        out[key] = {"value": nmt / dtm, "unit": "syndromes/s", "cores": threads,
+                    "sample": f"{nmt} syndromes, {dtm:.1f} s, OpenMP over syndromes, {host['model']}"}
     out["reference_python"] = {
         "value": REFERENCE_PYTHON_SYN_PER_S, "unit": "syndromes/s", "cores": 1, "kind": "reference",
         "measured_by_this_run": False,
@@ -93,6 +101,25 @@ def cpu_baseline(code, syndromes, prior, budget_s=12.0):
                   "50 iterations, 200 syndromes, 1 core of the BUILD container (8-vCPU Xeon @ 2.1 GHz); "
                   "the reference cannot travel to the GPU box"}
     return out
+
+
+def host_cpu_info():
+    """CPU model and core counts of this host (lscpu), and how many logical CPUs this process may use."""
+    import subprocess
+    info = {"model": "unknown", "physical_cores": os.cpu_count() or 1, "logical_cpus": os.cpu_count() or 1,
+            "usable_logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)}
+    try:
+        kv = {}
+        for ln in subprocess.check_output(["lscpu"], text=True, timeout=10).splitlines():
+            if ":" in ln:
+                a, b = ln.split(":", 1)
+                kv[a.strip()] = b.strip()
+        info["model"] = kv.get("Model name", "unknown")
+        info["physical_cores"] = int(kv.get("Core(s) per socket", "1")) * int(kv.get("Socket(s)", "1"))
+        info["logical_cpus"] = int(kv.get("CPU(s)", info["logical_cpus"]))
+    except Exception:
+        pass
+    return info
 
 
 # ---- FP64 vector-ALU roofline, measured by this run -------------------------------------------------
@@ -139,12 +166,38 @@ def shader_clock_ghz(device):
     return g2.value if L.ubench_clock_ghz2(device, ctypes.byref(g), ctypes.byref(g2)) == 0 else None
 
 
-def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, num_cu, iters_per_trip=1):
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")     # tools/profile_r03.sh -> tools/pmc_collect.py
+
+
+def committed_pmc(kernel_name):
+    """Counters of `kernel_name` from the committed rocprofv3 PMC summary (collected with tools/profile_r03.sh on
+    the same tree: PMC passes cannot run inside this process), or None."""
+    try:
+        allk = json.load(open(PMC_SUMMARY))
+    except Exception:
+        return None
+    short = kernel_name.replace("void ", "").split("(qbp::")[0]
+    for k, v in allk.items():
+        if short in k and "counters" in v:
+            return v
+    return None
+
+
+IDEAL_ISSUE_CYCLES = {"trans_f64": 16.0}         # every other class: 4 cycles per wave-instruction per SIMD
+FLOPS_PER_LANE = {"fma_f64": 2, "mul_f64": 1, "add_f64": 1}      # "useful" FP64 arithmetic (min/max, compares,
+#                                                                     conversions and reciprocal seeds not counted)
+
+
+def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, num_cu, iters_per_trip=1,
+                  costs=None):
     """Vector-ALU issue roofline.  needed = issue cycles of the kernel's own instructions: per wave
     and BP iteration, sum over classes of (instructions counted in the machine code of the loaded
     library) x (cycles one SIMD needs per instruction of that class, measured now), times the
     wave-iterations of a launch.  available = SIMDs x kernel time x the maximum shader clock.
-    frac = needed / available <= 1; achieved / peak are the same statement in lane-instructions/s."""
+    frac = needed / available <= 1; achieved / peak are the same statement in lane-instructions/s.
+    Beside it: the same fraction with the IDEAL costs (4 cycles, 16 for v_rcp_f64), the useful FP64 flop rate
+    against the 78.6 TFLOP/s vector peak, and -- from the committed PMC summary of the same kernel -- the
+    hardware's own instruction count and the HBM bytes per launch."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import valu_mix
     res = valu_mix.analyse(lib_path, [kernel_symbol])
@@ -157,14 +210,21 @@ def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, nu
     if "other_f64" in per_class:                                   # priced like an FMA
         per_class["fma_f64"] = per_class.get("fma_f64", 0) + per_class.pop("other_f64")
     n_total = mix["valu_total"]
-    cycles, rates = valu_issue_costs(device)
+    cycles, rates = costs if costs is not None else valu_issue_costs(device)
     issue_cycles = sum(n * cycles[c] for c, n in per_class.items())          # per wave-iteration
+    ideal_cycles = sum(n * IDEAL_ISSUE_CYCLES.get(c, 4.0) for c, n in per_class.items())
     n_simd = num_cu * 4
-    frac = issue_cycles * wave_iterations / (n_simd * kernel_s * MAX_CLOCK_HZ)
+    avail = n_simd * kernel_s * MAX_CLOCK_HZ
+    frac = issue_cycles * wave_iterations / avail
     achieved = n_total * wave_iterations * 64 / kernel_s                      # lane-instructions / s
-    return {
+    flops = sum(FLOPS_PER_LANE.get(c, 0) * n for c, n in per_class.items()) * 64 * wave_iterations / kernel_s
+    spec_peak = num_cu * 4 * 16 * 2 * MAX_CLOCK_HZ
+    out = {
         "bound": "fp64_valu", "achieved": achieved / 1e12, "peak": achieved / frac / 1e12,
         "unit": "Tlane-instr/s", "frac": frac, "traffic": None,
+        "self_measured": True,
+        "frac_ideal_pricing": ideal_cycles * wave_iterations / avail,
+        "flops_frac": flops / spec_peak, "useful_fp64_TFLOPs": flops / 1e12,
         "kernel": name, "kernel_ms": kernel_s * 1e3,
         "valu_insts_per_wave_iteration": n_total, "valu_by_class": per_class,
         "issue_cycles_per_inst_by_class": cycles,
@@ -172,16 +232,40 @@ def valu_roofline(lib_path, kernel_symbol, device, wave_iterations, kernel_s, nu
         "wave_iterations_per_launch": wave_iterations, "simds": n_simd, "max_clock_GHz": MAX_CLOCK_HZ / 1e9,
         "single_class_rates_Gwave_insts_per_s": {k: v / 1e9 for k, v in rates.items()},
         "fma_f64_stream_TFLOPs": rates["fma_f64"] * 64 * 2 / 1e12,
-        "spec_peak_TFLOPs_fp64_vector": num_cu * 4 * 16 * 2 * MAX_CLOCK_HZ / 1e12,
+        "spec_peak_TFLOPs_fp64_vector": spec_peak / 1e12,
         "how": "achieved: vector-ALU instructions per wave and BP iteration counted in the machine code of "
                "the loaded libqbp.so (tools/valu_mix.py: the kernel's main loop minus its once-per-syndrome "
-               "regions) x wave-iterations per launch / kernel time (HIP events on the launch stream).  peak: "
-               "the rate at which this instruction mix would issue if every issue cycle of every SIMD were "
-               "used at the maximum shader clock; the per-class issue costs (cycles per wave-instruction "
-               "per SIMD) are measured in this run with the hardware cycle counter "
-               "(tools/ubench/valu_rates.hip).  traffic (HBM bytes from PMC counters) cannot be collected "
-               "from inside the run: see profiles/ and DESIGN.md section 4",
+               "regions and the explicitly marked rare path) x wave-iterations per launch / kernel time (HIP "
+               "events on the launch stream).  peak: the rate at which this instruction mix would issue if "
+               "every issue cycle of every SIMD were used at the maximum shader clock; the per-class issue "
+               "costs (cycles per wave-instruction per SIMD) are measured in this run with the hardware cycle "
+               "counter (tools/ubench/valu_rates.hip).  frac_ideal_pricing: the same with 4 cycles per "
+               "instruction and 16 per v_rcp_f64.  flops_frac: useful FP64 flops (2 per fma, 1 per mul / add) "
+               "over the 78.6 TFLOP/s vector peak.  traffic and pmc: from the committed rocprofv3 PMC summary "
+               "of this kernel (PMC passes cannot run inside the bench process)",
     }
+    pm = committed_pmc(name)
+    if pm:
+        c = pm["counters"]
+        prov = os.path.relpath(PMC_SUMMARY, ROOT)
+        if "SQ_INSTS_VALU" in c:
+            per_wi = c["SQ_INSTS_VALU"]["last"] / wave_iterations
+            out["pmc"] = {"file": prov, "SQ_INSTS_VALU_per_wave_iteration": per_wi,
+                          "static_count_over_pmc_count": n_total / per_wi,
+                          "frac_with_pmc_count_ideal_pricing": (
+                              (c["SQ_INSTS_VALU"]["last"] - c.get("SQ_INSTS_VALU_TRANS_F64", {}).get("last", 0.0)) * 4.0
+                              + c.get("SQ_INSTS_VALU_TRANS_F64", {}).get("last", 0.0) * 16.0) / avail,
+                          "by_class_per_wave_iteration": {k: v["last"] / wave_iterations for k, v in c.items()
+                                                          if k.startswith("SQ_INSTS_")},
+                          "lds_bank_conflict_share": (c["SQ_LDS_BANK_CONFLICT"]["last"] / c["SQ_LDS_IDX_ACTIVE"]["last"]
+                                                      if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", {}).get("last") else None)}
+        if "hbm" in pm:
+            out["traffic"] = pm["hbm"]["traffic_bytes_per_launch"]
+            out["traffic_detail"] = dict(pm["hbm"], file=prov, unit="bytes per launch",
+                                         note="FETCH_SIZE x 2 (gfx950 correction for wide reads) + WRITE_SIZE, separate "
+                                              "PMC passes; against the algorithmic figure of hbm_effective this is "
+                                              "the syndrome / LLR I/O only")
+    return out
 
 
 def main():
@@ -287,6 +371,7 @@ def main():
             dist.all_reduce(counts)
         barrier()
         wall = time.perf_counter() - t0
+        timed.local_wall = wall                      # this rank's own clock around the same region
         if world > 1:
             w = torch.tensor([wall], dtype=torch.float64, device=dev)
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
@@ -296,6 +381,7 @@ def main():
 
     # ---- M2: forced 50 iterations (headline) ------------------------------------------------
     wall, kernel_ms, counts = timed(_lib.FLAG_FORCE_FULL, args.steps, args.warmup)
+    headline_local_wall = timed.local_wall
     clock_after_headline = shader_clock_ghz(local_rank)
     value = world * B * args.steps / wall
     bytes_per_launch = algorithmic_bytes(E, m, n, B * MAX_ITER, B)
@@ -319,9 +405,22 @@ def main():
         for _ in range(20):
             dist.all_reduce(t)
         torch.cuda.synchronize(dev)
+        ar_us = (time.perf_counter() - t0) / 20 * 1e6
+        wl = torch.zeros(world, dtype=torch.float64, device=dev)
+        wl[rank] = headline_local_wall
+        dist.all_reduce(wl)
+        ms_step = 1e3 * wall / args.steps
+        # per rank: its kernel time, the rate it alone sustained over the timed region, and the share of a step
+        # the one collective of the path (an int64 all-reduce of the counts) takes -- so that the N = 1 line can be
+        # checked against the single-GPU bench and N = 8 against 8 x N = 1
         multi = {"n_ranks_seen": dist.get_world_size(), "backend": args.backend,
                  "kernel_ms_per_rank": [float(x) for x in km.tolist()],
-                 "all_reduce_us": (time.perf_counter() - t0) / 20 * 1e6}
+                 "wall_s_per_rank": [float(x) for x in wl.tolist()],
+                 "value_per_rank": [B * args.steps / float(x) for x in wl.tolist()],
+                 "sum_of_value_per_rank": float(sum(B * args.steps / float(x) for x in wl.tolist())),
+                 "all_reduce_us": ar_us,
+                 "all_reduce_share_of_step": ar_us * 1e-3 / ms_step,
+                 "kernel_share_of_step_per_rank": [float(x) / ms_step for x in km.tolist()]}
 
     # ---- M1: reference semantics (early exit) -----------------------------------------------
     early = stress = sustained = None
@@ -419,6 +518,18 @@ def main():
     dropin = None
     if full and world == 1:
         dropin = dropin_leg(code, local_rank)
+    costs = None
+    others = None
+    if rank == 0:
+        try:
+            costs = valu_issue_costs(local_rank)
+        except Exception:
+            costs = None
+    if full and world == 1 and costs is not None:
+        try:
+            others = other_config_legs(local_rank, costs, dec.info("num_cu"))
+        except Exception as ex:
+            others = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         dc = 6 if (dec.info("max_row_deg") <= 6 and dec.info("max_col_deg") <= 3) else 8
@@ -430,7 +541,7 @@ def main():
             if kernel_kind != 1:
                 raise RuntimeError(f"the headline ran kernel kind {kernel_kind}, not the on-chip kernel")
             roof = valu_roofline(_lib.LIB_PATH, symbol, local_rank, wave_iters, kernel_ms * 1e-3,
-                                 dec.info("num_cu"), iters_per_trip=2 if one_bar else 1)
+                                 dec.info("num_cu"), iters_per_trip=2 if one_bar else 1, costs=costs)
             roof["bp_iterations_per_loop_trip"] = 2 if one_bar else 1
             roof["shader_clock_GHz_right_after"] = clock_after_headline
         except Exception as ex:             # a bench line without a roofline is still a bench line
@@ -461,6 +572,7 @@ def main():
             "stress_p010": stress,
             "sustained": sustained,
             "hbm_streamed_variant": streamed,
+            "other_configs": others,
             "dropin_api": dropin,
             "converged_fraction": counts[0] / (world * B),
         }
@@ -470,6 +582,155 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def fused_symbol(variant, forced, one_bar, mc=False):
+    return (f"bp_fused_kernelILi6ELi3ELi{variant}ELb{int(mc)}ELb{int(forced)}ELi1024ELi1ELb{int(one_bar)}EE")
+
+
+def other_config_legs(device, costs, num_cu):
+    """The other BASELINE.json configurations on one GPU, each with the same issue-roofline accounting as the
+    headline: config 2 ([[72,12,6]], p = 0.01, 10 000 syndromes) and config 3 ([[144,12,12]], min-sum alpha 0.8 /
+    damping 0.7 / clip 25, 100 000 syndromes), early exit (reference semantics) and forced 50; the device-resident
+    Monte-Carlo loop of config 4 / 5 ([[288,12,18]]: sample + decode + classify, with and without OSD-0); the OSD-0
+    kernel alone.  Inputs resident in HBM, HIP events on the launch stream."""
+    import torch
+
+    from qldpc_amd import _lib, bp, codes, mc
+    dev = torch.device("cuda", device)
+    st = torch.cuda.current_stream(dev)
+    legs = {}
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize(dev)
+        ms = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st); fn(); b.record(st); torch.cuda.synchronize(dev)
+            ms.append(a.elapsed_time(b))
+        return float(np.median(ms))
+
+    for tag, name, p, B, variant, kw in (
+            ("config2", "[[72, 12, 6]]", 0.01, 10_000, _lib.SUM_PRODUCT, dict(alpha=1.0, damping=1.0, clip=20.0)),
+            ("config3", "[[144, 12, 12]]", 0.05, 100_000, _lib.MIN_SUM, dict(alpha=0.8, damping=0.7, clip=25.0))):
+        code = codes.load_code(name)
+        m, n = code.Hx.shape
+        E = int(code.Hx.sum())
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        err = torch.rand((B, n), generator=g, device=dev) < p
+        Ht = torch.from_numpy(np.ascontiguousarray(code.Hx.T).astype(np.float32)).to(dev)
+        syn = (err.float() @ Ht).remainder_(2).to(torch.uint8).contiguous()
+        prior = torch.full((n,), float(np.log((1 - p) / p)), dtype=torch.float64, device=dev)
+        hard = torch.empty((B, n), dtype=torch.uint8, device=dev); conv = torch.empty((B,), dtype=torch.uint8, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev); llr = torch.empty((B, n), dtype=torch.float64, device=dev)
+        dec = bp.decoder_for(code.Hx, device=device)
+        leg = {"workload": f"{name} p={p} B={B} variant={int(variant)} " + " ".join(f"{k}={v}" for k, v in kw.items())}
+        for mode, flags in (("early_exit", 0), ("forced_50", _lib.FLAG_FORCE_FULL)):
+            def run():
+                dec.decode_device(syn.data_ptr(), prior.data_ptr(), B, MAX_ITER, variant, kw["alpha"], kw["damping"],
+                                  kw["clip"], flags, hard.data_ptr(), conv.data_ptr(), iters.data_ptr(),
+                                  llr.data_ptr(), st.cuda_stream)
+            ms = timed(run)
+            it_total = int(iters.sum(dtype=torch.int64).item()) + B if not flags else B * MAX_ITER
+            threads = dec.info("threads")
+            S, waves = max(1, threads // m), (threads + 63) // 64
+            one_bar = int(dec.info("one_barrier")) if flags else 0
+            r = {"value": B / ms * 1e3, "unit": "syndromes/s", "kernel_ms": ms,
+                 "mean_iterations": it_total / B, "converged_fraction": float(conv.float().mean().item())}
+            try:
+                roof = valu_roofline(_lib.LIB_PATH, fused_symbol(int(variant), bool(flags), one_bar), device,
+                                     it_total / S * waves, ms * 1e-3, num_cu, iters_per_trip=2 if one_bar else 1,
+                                     costs=costs)
+                r["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                      "frac_ideal_pricing", "flops_frac", "kernel",
+                                                      "valu_insts_per_wave_iteration")}
+                if not flags:
+                    r["roofline"]["note"] = ("per-iteration instructions only: the once-per-syndrome work (load, "
+                                             "emit, work fetch) is not in the count, so frac understates the issue "
+                                             "share at few iterations per syndrome")
+            except Exception as ex:
+                r["roofline"] = {"bound": "fp64_valu", "frac": None, "error": f"{type(ex).__name__}: {ex}"}
+            r["hbm_effective_GBps"] = algorithmic_bytes(E, m, n, it_total, B) / (ms * 1e-3) / 1e9
+            leg[mode] = r
+        legs[tag] = leg
+
+    # ---- Monte-Carlo loop and OSD-0 of [[288,12,18]] ----------------------------------------------------------
+    code = codes.load_code(CODE)
+    m, n = code.Hx.shape
+    dec = bp.decoder_for(code.Hx, device=device)
+    mcl = {}
+    for p, T, flags, tag in ((0.01, 4 << 20, 0, "p0.01"), (0.05, 1 << 20, 0, "p0.05"),
+                             (0.05, 1 << 20, _lib.FLAG_OSD0, "p0.05_osd0")):
+        prior = torch.from_numpy(mc.prior_of(p, n)).to(dev)
+        cnt = torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev)
+
+        def run():
+            for a in range(0, T, 1 << 20):
+                dec.mc_run_device(code.Lx, code.distance, p, prior.data_ptr(), a, min(a + (1 << 20), T),
+                                  cnt.data_ptr(), max_iter=MAX_ITER, flags=flags, stream=st.cuda_stream)
+        run(); torch.cuda.synchronize(dev); cnt.zero_()
+        ms = timed(run, reps=3)
+        c = (cnt // 3).cpu().numpy()
+        it_total = int(c[7] + c[0])
+        threads = dec.info("threads")
+        S, waves = max(1, threads // m), (threads + 63) // 64
+        r = {"value": T / ms * 1e3, "unit": "trials/s", "ms": ms, "ler": float(c[1] / c[0]),
+             "not_converged": float(c[6] / c[0]), "mean_iterations": it_total / T}
+        try:
+            roof = valu_roofline(_lib.LIB_PATH, fused_symbol(0, False, 0, mc=True), device, it_total / S * waves,
+                                 ms * 1e-3, num_cu, costs=costs)
+            r["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                  "frac_ideal_pricing", "flops_frac", "kernel",
+                                                  "valu_insts_per_wave_iteration")}
+            r["roofline"]["note"] = ("BP iterations only; sampling (Philox), classification and -- with OSD-0 -- the "
+                                     "second kernel are inside `ms` but not in the instruction count")
+        except Exception as ex:
+            r["roofline"] = {"bound": "fp64_valu", "frac": None, "error": f"{type(ex).__name__}: {ex}"}
+        mcl[tag] = r
+    legs["monte_carlo_288"] = mcl
+
+    # OSD-0 alone: BP failures of a p = 0.1 batch
+    B = 131072
+    p = 0.1
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    err = torch.rand((B, n), generator=g, device=dev) < p
+    Ht = torch.from_numpy(np.ascontiguousarray(code.Hx.T).astype(np.float32)).to(dev)
+    syn = (err.float() @ Ht).remainder_(2).to(torch.uint8).contiguous()
+    prior = torch.full((n,), float(np.log((1 - p) / p)), dtype=torch.float64, device=dev)
+    hard = torch.empty((B, n), dtype=torch.uint8, device=dev); conv = torch.empty((B,), dtype=torch.uint8, device=dev)
+    iters = torch.empty((B,), dtype=torch.int32, device=dev); llr = torch.empty((B, n), dtype=torch.float64, device=dev)
+    sol = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    dec.decode_device(syn.data_ptr(), prior.data_ptr(), B, MAX_ITER, 0, 1.0, 1.0, 20.0, 0, hard.data_ptr(),
+                      conv.data_ptr(), iters.data_ptr(), llr.data_ptr(), st.cuda_stream)
+    ms = timed(lambda: dec.osd0_device(syn.data_ptr(), llr.data_ptr(), hard.data_ptr(), B, sol.data_ptr(), st.cuda_stream),
+               reps=3)
+    ok = bool((((sol.float() @ Ht).remainder_(2).to(torch.uint8)) == syn).all())
+    osd = {"value": B / ms * 1e3, "unit": "OSD-0 solutions/s", "kernel_ms": ms, "B": B,
+           "all_solutions_reproduce_their_syndrome": ok}
+    pm = committed_pmc("osd0_kernel")
+    if pm:
+        c = {k: v["last"] for k, v in pm["counters"].items()}
+        wc = c.get("SQ_WAVE_CYCLES")
+        if wc:
+            # (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count in the same unit: shares are unit-free)
+            osd["roofline"] = {
+                "bound": "lds_latency", "achieved": B / ms * 1e3, "peak": None, "unit": "OSD-0 solutions/s",
+                "frac": None, "traffic": None,
+                "pmc_file": os.path.relpath(PMC_SUMMARY, ROOT),
+                "wave_cycle_shares": {"waiting (s_waitcnt / barrier)": c.get("SQ_WAIT_ANY", 0) / wc,
+                                      "issue stalled": c.get("SQ_WAIT_INST_ANY", 0) / wc,
+                                      "issuing any instruction": c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                                      "issuing LDS": c.get("SQ_ACTIVE_INST_LDS", 0) / wc,
+                                      "issuing VALU": c.get("SQ_ACTIVE_INST_VALU", 0) / wc},
+                "lds_bank_conflict_share": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+                                            if c.get("SQ_LDS_IDX_ACTIVE") else None),
+                "insts_per_solution": {"valu": c.get("SQ_INSTS_VALU", 0) / B, "lds": c.get("SQ_INSTS_LDS", 0) / B,
+                                       "salu": c.get("SQ_INSTS_SALU", 0) / B},
+                "note": "one wavefront per syndrome: Gauss-Jordan elimination over bit-packed rows in LDS is a chain "
+                        "of dependent LDS round trips (pivot search, row XOR); the counters say where the wave "
+                        "cycles go (DESIGN.md section 4)"}
+    legs["osd0_288"] = osd
+    return legs
 
 
 def dropin_leg(code, device, p=0.05, batch=5000, batches=4, max_iter=150):

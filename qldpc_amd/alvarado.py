@@ -27,7 +27,12 @@ def slope_through_origin(x, f):
     """argmin_a sum (f - a x)^2."""
     x = np.asarray(x, np.float64)
     f = np.asarray(f, np.float64)
-    return float(np.dot(x, f) / np.dot(x, x))
+    xx = float(np.dot(x, x))
+    if x.size == 0 or xx == 0.0:
+        # (the reference's curve_fit raises on an empty / degenerate data set; a silent 0 / 0 = NaN here
+        # would be handed on as the min-sum normalisation)
+        raise ValueError("alpha fit: no bin is populated by both message classes (nothing to fit)")
+    return float(np.dot(x, f) / xx)
 
 
 def alpha_from_histograms(edges, count0, count1):

@@ -65,12 +65,27 @@ def csr_from_H(H):
     return row_ptr, np.ascontiguousarray(cols, np.int32), int(A.shape[0]), int(A.shape[1])
 
 
-# Dense matrices above this size (the reference's space-time matrices: 2592 x 7776 float64 = 161 MB,
-# passed again on every one-syndrome call of studies/studyTT.py) are recognised by identity plus a
-# sampled checksum instead of a hash of all their bytes (30 ms per call for that matrix, against a
-# 0.1 - 0.9 ms decode).  QBP_STRICT_HASH=1 restores the full hash for every call.
+# The decoder cache is keyed by the CONTENT of H: every call hashes the matrix (0.2 ms for the BB codes; 30 ms
+# for the reference's 2592 x 7776 float64 space-time matrix, against a 0.1 - 0.9 ms decode).  Two ways around
+# the hash, both explicit:
+#   * keep the handle:  dec = qldpc_amd.bp.decoder_for(H); dec.decode(...)        (no lookup at all), or
+#   * QBP_TRUST_IDENTITY=1 (or qldpc_amd.bp.TRUST_IDENTITY = True): an array that is the very object and
+#     buffer seen before is trusted -- large writeable ones after a checksum of ~64k evenly spaced
+#     elements, which an in-place edit between two calls can miss: call forget(H) after editing such a matrix.
+# Without the switch only arrays that cannot change are recognised by identity: read-only arrays whose whole
+# chain of bases is read-only too (a read-only VIEW of a writeable array can change under it).
 _FULL_HASH_LIMIT = 1 << 20
-_STRICT = os.environ.get("QBP_STRICT_HASH", "0") not in ("0", "")
+TRUST_IDENTITY = os.environ.get("QBP_TRUST_IDENTITY", "0") not in ("0", "")
+_STRICT = os.environ.get("QBP_STRICT_HASH", "0") not in ("0", "")     # (overrides TRUST_IDENTITY)
+
+
+def _immutable(A):
+    """A read-only ndarray none of whose bases is writeable."""
+    while isinstance(A, np.ndarray):
+        if A.flags.writeable:
+            return False
+        A = A.base
+    return A is None or isinstance(A, (bytes, memoryview)) and getattr(A, "readonly", True)
 
 
 def _fingerprint(H, sparse):
@@ -103,9 +118,10 @@ def decoder_for(H, device=None) -> _lib.Decoder:
     """Decoder handle for H, cached on the matrix content (the reference re-derives the graph on
     every call; here that happens once per code).
 
-    Lookup: a read-only array, or a large one (see _FULL_HASH_LIMIT), that is the very object and
-    buffer seen before is trusted (large writeable ones after a sampled checksum); everything else is
-    hashed in full on every call, so an in-place change of a small matrix is always noticed.
+    Lookup: the matrix is hashed in full on every call, so an in-place change is always noticed; only an
+    array that cannot change (read-only down its whole chain of bases) is recognised by identity.
+    QBP_TRUST_IDENTITY=1 extends that to large writeable arrays after a sampled checksum (see the comment
+    above _FULL_HASH_LIMIT: opt-in, because an edit can slip through the sample).
 
     The cache only holds references: an evicted Decoder stays usable by whoever still holds it and
     its device handle is destroyed when the last reference goes (``Decoder.__del__``).  Every
@@ -123,12 +139,14 @@ def _decoder_for(H, device):
     except Exception:  # pragma: no cover
         sparse = False
     fp = _fingerprint(H, sparse)
-    big = fp is not None and H.nbytes > _FULL_HASH_LIMIT and not _STRICT
+    trust = TRUST_IDENTITY and not _STRICT
+    big = trust and fp is not None and H.nbytes > _FULL_HASH_LIMIT
+    frozen = fp is not None and _immutable(H)
     sample = None
-    if fp is not None and (big or not H.flags.writeable):
+    if fp is not None and (big or frozen):
         hit = _BY_ID.get((id(H), device))
         if hit is not None and hit[0]() is H and hit[1] == fp and hit[2] in _DECODERS:
-            if not H.flags.writeable:
+            if frozen:
                 return _DECODERS[hit[2]]
             sample = _sample_digest(H)
             if sample == hit[3]:
@@ -148,12 +166,12 @@ def _decoder_for(H, device):
         if len(_DECODERS) >= _MAX_CACHED:
             _DECODERS.pop(next(iter(_DECODERS)))       # drop the reference only (see docstring)
         _DECODERS[key] = dec
-    if fp is not None and (big or not H.flags.writeable):
+    if fp is not None and (big or frozen):
         import weakref
         if len(_BY_ID) > 4 * _MAX_CACHED:
             _BY_ID.clear()
         try:
-            if big and H.flags.writeable and sample is None:
+            if big and not frozen and sample is None:
                 sample = _sample_digest(H)
             _BY_ID[(id(H), device)] = (weakref.ref(H), fp, key, sample)
         except TypeError:  # pragma: no cover
@@ -289,36 +307,59 @@ def performBeliefPropagationGPU(H, syndrome, initialBelief, verbose=False, maxIt
 class _LastBatch:
     """What `performOSD` needs to serve the reference driver's loop (paperResults_GPU.py:113-123: one
     OSD call per sample BP did not converge on, with rows of the arrays returned below) from ONE
-    batched OSD launch: see qldpc_amd/osd.py.  Holds the syndromes (the shim's own int8 copy or the
-    caller's int8 array), the returned arrays (so their memory cannot be recycled while rows are
-    recognised by address; batches above _LAST_BATCH_LIMIT bytes of LLRs are not remembered) and --
-    once the first such call arrives -- the gathered inputs and solutions of all failing rows."""
-    __slots__ = ("dec", "syn", "llr", "hard", "conv", "addr", "rowbytes", "rows", "pos", "inputs",
-                 "solutions", "lock")
+    batched OSD launch: see qldpc_amd/osd.py.
+
+    Lifetime: the record is per THREAD (a thread pool's workers do not overwrite each other's
+    batch); it holds the returned LLR / hard arrays only WEAKLY -- rows are recognised by address, which is
+    only meaningful while the caller still holds the arrays; once they are gone the record is dead and
+    nothing is kept alive -- plus the syndromes (B x m bytes) and, once the first OSD call arrives, its own
+    gathered copies of the failing rows and their solutions; it is dropped when every failing row has been
+    served, at the next batch call of the thread, or never created with QBP_NO_LAST_BATCH=1
+    (qldpc_amd.bp.REMEMBER_LAST_BATCH = False)."""
+    __slots__ = ("dec", "syn", "llr_ref", "hard_ref", "conv", "addr", "rowbytes", "rows", "pos", "inputs",
+                 "solutions", "lock", "served", "n_fail")
 
     def __init__(self, dec, syn, llr, hard, conv):
+        import weakref
         self.dec, self.syn, self.conv = dec, syn, conv.copy()
-        self.llr, self.hard = llr, hard
+        self.llr_ref, self.hard_ref = weakref.ref(llr), weakref.ref(hard)
         self.addr = llr.__array_interface__["data"][0]
         self.rowbytes, self.rows = llr.strides[0], llr.shape[0]
         self.pos = self.inputs = self.solutions = None
         self.lock = threading.Lock()
+        self.served, self.n_fail = set(), int((~conv).sum())
+
+    @property
+    def llr(self):
+        return self.llr_ref()
+
+    @property
+    def hard(self):
+        return self.hard_ref()
 
 
-_LAST_BATCH = None
-_LAST_BATCH_LIMIT = 256 << 20
+REMEMBER_LAST_BATCH = os.environ.get("QBP_NO_LAST_BATCH", "0") in ("0", "")
+_LAST_BATCH_LIMIT = 256 << 20          # larger batches are not remembered (their failing rows alone are big)
+_TLS = threading.local()
+
+
+def _last_batch():
+    return getattr(_TLS, "last_batch", None)
+
+
+def _set_last_batch(lb):
+    _TLS.last_batch = lb
 
 
 def performBeliefPropagationBatch(H, syndromes, initialBelief, maxIter=50):
     """decoding/beliefPropagationGPU.py:81-178 -> (int8[B, n], bool[B], float64[B, n])."""
-    global _LAST_BATCH
     dec = decoder_for(H)
     syn = _syndromes(syndromes, dec.m, batch=True)
     hard, conv, _, llr = dec.decode(syn.view(np.uint8), _prior(initialBelief, dec.n),
                                     _check_iter(maxIter))
     hard = hard.view(np.int8)                   # (0/1 bytes of a fresh array: no copy)
-    keep = 1 < len(conv) and llr.nbytes <= _LAST_BATCH_LIMIT and not conv.all()
-    _LAST_BATCH = _LastBatch(dec, syn, llr, hard, conv) if keep else None
+    keep = REMEMBER_LAST_BATCH and 1 < len(conv) and llr.nbytes <= _LAST_BATCH_LIMIT and not conv.all()
+    _set_last_batch(_LastBatch(dec, syn, llr, hard, conv) if keep else None)
     return hard, conv, llr
 
 

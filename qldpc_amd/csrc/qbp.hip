@@ -700,6 +700,7 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
         G.lx_cols = mc->lx_cols; G.trial_begin = mc->trial_begin; G.seed = mc->seed;
         G.threshold = mc->threshold; G.draws = mc->draws; G.half_distance = mc->half_distance;
         G.counters = mc->counters; G.wsE = h->d_wsE.p;
+        G.errors_in = mc->errors_in;
         G.fail_list = mc->fail_list; G.fail_count = mc->fail_count; G.fail_syn = mc->fail_syn;
         G.fail_llr = mc->fail_llr; G.fail_hard = mc->fail_hard; G.fail_err = mc->fail_err;
         HIP_TRY(qbp::launch_generic(true, g.mem, variant, G, g.grid, g.threads, g.lds, s));
@@ -1072,65 +1073,72 @@ try {
     // Outputs: device -> pinned staging (DMA at PCIe rate) -> the caller's arrays (memcpy), in chunks
     // of up to 32 MiB, the host copy of one chunk overlapping the DMA of the next.  (A direct copy
     // into pageable memory goes through the runtime's own small staging buffers at a fraction of
-    // that rate.)
-    {
+    // that rate.)  The two staging buffers are as large as the largest chunk any call of this handle has
+    // needed, never more than 32 MiB each (they used to be 32 MiB from the first 256 KiB call on).
+    auto copy_out = [&]() -> int {
         const size_t per = (hard ? n : 0) + (converged ? 1 : 0) + (iters ? 4 : 0) + (llr ? 8 * n : 0);
         constexpr size_t STAGE = (size_t)32 << 20;
-        if (per > 0) {
-            if (h->stage_bytes < STAGE) {
-                for (int i = 0; i < 2; ++i) {
-                    if (h->stage[i]) (void)hipHostFree(h->stage[i]);
-                    h->stage[i] = nullptr;
-                }
-                h->stage_bytes = 0;
-                for (int i = 0; i < 2; ++i) {
-                    HIP_TRY(hipHostMalloc(&h->stage[i], STAGE + 64, hipHostMallocDefault));
-                    if (!h->stage_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
-                }
-                h->stage_bytes = STAGE;
+        if (per == 0) return QBP_OK;
+        // (pieces of at least 1 MiB, at least four of them above 4 MiB: the reference driver's 13 MB per
+        // batch then overlap their DMA with the copy-out instead of running one after the other)
+        const size_t quarter = std::max<size_t>((b + 3) / 4, ((size_t)1 << 20) / per + 1);
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>({b, STAGE / (per + 8), quarter}));
+        const size_t need = std::min<size_t>(STAGE, chunk * (per + 8) + 64);
+        if (h->stage_bytes < need) {
+            for (int i = 0; i < 2; ++i) {
+                if (h->stage[i]) (void)hipHostFree(h->stage[i]);
+                h->stage[i] = nullptr;
             }
-            // (pieces of at least 1 MiB, at least four of them above 4 MiB: the reference driver's 13 MB per
-            // batch then overlap their DMA with the copy-out instead of running one after the other)
-            const size_t quarter = std::max<size_t>((b + 3) / 4, ((size_t)1 << 20) / per + 1);
-            const size_t chunk = std::max<size_t>(1, std::min<size_t>({b, STAGE / (per + 8), quarter}));
-            struct Piece { size_t b0, cnt; };
-            Piece prev{0, 0};
-            auto offsets = [&](size_t cnt, size_t& o_llr, size_t& o_it, size_t& o_hard, size_t& o_conv) {
-                o_llr = 0;
-                o_it = o_llr + (llr ? cnt * n * 8 : 0);
-                o_hard = o_it + (iters ? ((cnt * 4 + 7) & ~(size_t)7) : 0);
-                o_conv = o_hard + (hard ? cnt * n : 0);
-            };
-            auto drain = [&](const Piece& pc, int slot) -> int {
-                if (pc.cnt == 0) return QBP_OK;
-                HIP_TRY(hipEventSynchronize(h->stage_ev[slot]));
-                const uint8_t* st = static_cast<const uint8_t*>(h->stage[slot]);
-                size_t o_llr, o_it, o_hard, o_conv;
-                offsets(pc.cnt, o_llr, o_it, o_hard, o_conv);
-                if (llr) std::memcpy(llr + pc.b0 * n, st + o_llr, pc.cnt * n * 8);
-                if (iters) std::memcpy(iters + pc.b0, st + o_it, pc.cnt * 4);
-                if (hard) std::memcpy(hard + pc.b0 * n, st + o_hard, pc.cnt * n);
-                if (converged) std::memcpy(converged + pc.b0, st + o_conv, pc.cnt);
-                return QBP_OK;
-            };
-            int slot = 0;
-            for (size_t b0 = 0; b0 < b; b0 += chunk, slot ^= 1) {
-                const size_t cnt = std::min(chunk, b - b0);
-                uint8_t* st = static_cast<uint8_t*>(h->stage[slot]);
-                size_t o_llr, o_it, o_hard, o_conv;
-                offsets(cnt, o_llr, o_it, o_hard, o_conv);
-                if (llr) HIP_TRY(hipMemcpyAsync(st + o_llr, h->d_llr.p + b0 * n, cnt * n * 8, hipMemcpyDeviceToHost, s));
-                if (iters) HIP_TRY(hipMemcpyAsync(st + o_it, h->d_iters.p + b0, cnt * 4, hipMemcpyDeviceToHost, s));
-                if (hard) HIP_TRY(hipMemcpyAsync(st + o_hard, h->d_hard.p + b0 * n, cnt * n, hipMemcpyDeviceToHost, s));
-                if (converged) HIP_TRY(hipMemcpyAsync(st + o_conv, h->d_conv.p + b0, cnt, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipEventRecord(h->stage_ev[slot], s));
-                rc = drain(prev, slot ^ 1);          // the previous chunk, while this one is in flight
-                if (rc) return rc;
-                prev = Piece{b0, cnt};
+            h->stage_bytes = 0;
+            const size_t want = std::min<size_t>(STAGE, std::max<size_t>(need, (size_t)1 << 20));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipHostMalloc(&h->stage[i], want + 64, hipHostMallocDefault));
+                if (!h->stage_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
             }
-            rc = drain(prev, slot ^ 1);
-            if (rc) return rc;
+            h->stage_bytes = want;
         }
+        struct Piece { size_t b0, cnt; };
+        Piece prev{0, 0};
+        auto offsets = [&](size_t cnt, size_t& o_llr, size_t& o_it, size_t& o_hard, size_t& o_conv) {
+            o_llr = 0;
+            o_it = o_llr + (llr ? cnt * n * 8 : 0);
+            o_hard = o_it + (iters ? ((cnt * 4 + 7) & ~(size_t)7) : 0);
+            o_conv = o_hard + (hard ? cnt * n : 0);
+        };
+        auto drain = [&](const Piece& pc, int slot) -> int {
+            if (pc.cnt == 0) return QBP_OK;
+            HIP_TRY(hipEventSynchronize(h->stage_ev[slot]));
+            const uint8_t* st = static_cast<const uint8_t*>(h->stage[slot]);
+            size_t o_llr, o_it, o_hard, o_conv;
+            offsets(pc.cnt, o_llr, o_it, o_hard, o_conv);
+            if (llr) std::memcpy(llr + pc.b0 * n, st + o_llr, pc.cnt * n * 8);
+            if (iters) std::memcpy(iters + pc.b0, st + o_it, pc.cnt * 4);
+            if (hard) std::memcpy(hard + pc.b0 * n, st + o_hard, pc.cnt * n);
+            if (converged) std::memcpy(converged + pc.b0, st + o_conv, pc.cnt);
+            return QBP_OK;
+        };
+        int slot = 0;
+        for (size_t b0 = 0; b0 < b; b0 += chunk, slot ^= 1) {
+            const size_t cnt = std::min(chunk, b - b0);
+            uint8_t* st = static_cast<uint8_t*>(h->stage[slot]);
+            size_t o_llr, o_it, o_hard, o_conv;
+            offsets(cnt, o_llr, o_it, o_hard, o_conv);
+            if (llr) HIP_TRY(hipMemcpyAsync(st + o_llr, h->d_llr.p + b0 * n, cnt * n * 8, hipMemcpyDeviceToHost, s));
+            if (iters) HIP_TRY(hipMemcpyAsync(st + o_it, h->d_iters.p + b0, cnt * 4, hipMemcpyDeviceToHost, s));
+            if (hard) HIP_TRY(hipMemcpyAsync(st + o_hard, h->d_hard.p + b0 * n, cnt * n, hipMemcpyDeviceToHost, s));
+            if (converged) HIP_TRY(hipMemcpyAsync(st + o_conv, h->d_conv.p + b0, cnt, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(h->stage_ev[slot], s));
+            const int rc2 = drain(prev, slot ^ 1);          // the previous chunk, while this one is in flight
+            if (rc2) return rc2;
+            prev = Piece{b0, cnt};
+        }
+        return drain(prev, slot ^ 1);
+    };
+    rc = copy_out();
+    if (rc) {
+        // (copies into the staging buffers may still be in flight: the next call must not find them so)
+        (void)hipStreamSynchronize(s);
+        return rc;
     }
     HIP_TRY(hipStreamSynchronize(s));
     return QBP_OK;

@@ -27,13 +27,16 @@ def _from_last_batch(dec, syn, l, hd):
     checking that the arguments still hold exactly the values the solution was computed from (OSD is a
     pure function of them).  Anything else (other arrays, changed contents, converged rows) returns None
     and takes the one-syndrome path."""
-    lb = bp._LAST_BATCH
+    lb = bp._last_batch()
     if lb is None or lb.dec is not dec or not isinstance(l, np.ndarray) or not l.flags.c_contiguous:
+        return None
+    L, Hd = lb.llr, lb.hard
+    if L is None or Hd is None:                      # the caller let go of the batch's arrays: nothing to recognise
+        bp._set_last_batch(None)
         return None
     off = l.__array_interface__["data"][0] - lb.addr
     if off < 0 or off % lb.rowbytes or off // lb.rowbytes >= lb.rows:
         return None
-    L, Hd = lb.llr, lb.hard
     with lb.lock:
         if lb.solutions is None:
             idx = np.flatnonzero(~lb.conv)
@@ -42,13 +45,18 @@ def _from_last_batch(dec, syn, l, hd):
             lb.inputs = inputs
             lb.pos = np.full(lb.rows, -1, np.int64)
             lb.pos[idx] = np.arange(len(idx))
-    k = lb.pos[off // lb.rowbytes]
+    row = off // lb.rowbytes
+    k = lb.pos[row]
     if k < 0:
         return None
     s_in, l_in, h_in = lb.inputs
     if not (np.array_equal(l, l_in[k]) and np.array_equal(hd, h_in[k]) and np.array_equal(syn, s_in[k])):
         return None
-    return lb.solutions[k].astype(np.int64)
+    sol = lb.solutions[k].astype(np.int64)
+    lb.served.add(int(row))
+    if len(lb.served) >= lb.n_fail:                  # every failing row answered: the record has done its job
+        bp._set_last_batch(None)
+    return sol
 
 
 def performOSD(H, syndrome, llr, hard):

@@ -78,3 +78,14 @@ def test_closed_form_fit_is_the_references_fit():
         c1, _ = np.histogram(m1, bins=50, range=rng_)
         got = alvarado.alpha_from_histograms(edges, c0, c1)
         assert got == pytest.approx(want, rel=1e-9)
+
+
+def test_fit_without_common_bins_raises_like_the_reference():
+    """when no histogram bin holds messages of both classes the reference's curve_fit raises
+    (rework/Alvarado.py:55-62); the closed form must not return NaN instead."""
+    from qldpc_amd import alvarado
+    edges = np.linspace(-1.0, 1.0, 5)
+    with pytest.raises(ValueError, match="both message classes"):
+        alvarado.alpha_from_histograms(edges, np.array([5, 3, 0, 0]), np.array([0, 0, 2, 7]))
+    with pytest.raises(ValueError):
+        alvarado.slope_through_origin([0.0, 0.0], [1.0, 2.0])

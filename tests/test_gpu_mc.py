@@ -115,6 +115,13 @@ def test_bench_two_rank_path(tmp_path):
     assert line["multi_gpu"]["all_reduce_us"] > 0
     # (two ranks time-share one GPU and synchronise over gloo: not a performance number)
     assert line["value"] > 1e5 and line["config"]["syndromes_per_gpu_per_step"] == 8000
+    # the accounting the driver's N-GPU lines can be checked with: value = n_gpus x syndromes per GPU and step
+    # x steps / wall (max over ranks), per-rank rates and the share of a step the one all-reduce takes
+    wall = line["ms_per_step"] * 1e-3 * line["steps"]
+    assert abs(line["n_gpus"] * 8000 * line["steps"] / wall - line["value"]) <= 1e-6 * line["value"]
+    mg = line["multi_gpu"]
+    assert len(mg["value_per_rank"]) == 2 and all(v >= 0.99 * line["value"] / 2 for v in mg["value_per_rank"])
+    assert 0 < mg["all_reduce_share_of_step"] < 1 and len(mg["kernel_share_of_step_per_rank"]) == 2
 
 
 def test_mc_two_rank_self_launch(tmp_path):

@@ -265,9 +265,9 @@ def test_driver_loop_through_the_dropin_equals_single_calls():
     for i in fails:
         got[int(i)] = osd.performOSD_enhanced(H, syndromes[i], llrs_batch[i], detections[i], order=7)
         if before is None:
-            before = bp._LAST_BATCH.solutions
+            before = bp._last_batch().solutions
             assert before is not None and len(before) == len(fails)
-    assert bp._LAST_BATCH.solutions is before                  # computed once
+    assert bp._last_batch() is None                            # every failing row served: the record is gone
     for i in fails[::7]:
         single = osd.performOSD(H, syndromes[i].copy(), llrs_batch[i].copy(), detections[i].copy())
         assert got[int(i)].dtype == np.int64 and np.array_equal(got[int(i)], single)

@@ -292,9 +292,12 @@ def test_self_launch_command_and_supervisor(tmp_path):
 
 
 def test_decoder_cache_lookup_rules(monkeypatch):
-    """qldpc_amd.bp.decoder_for without a device (Decoder stubbed): small matrices are re-hashed on every
-    call (an in-place change gives a new decoder); a large dense matrix that is the same object is
-    trusted after a sampled checksum, and `forget` drops it; eviction only drops the cache's reference."""
+    """qldpc_amd.bp.decoder_for without a device (Decoder stubbed).  Default: every matrix is hashed in full on
+    every call, so an in-place edit ANYWHERE in a large matrix is noticed (the old default
+    trusted identity + a sampled checksum, which an edit off the sample grid slipped through); only arrays
+    that cannot change are recognised by identity -- a read-only view of a writeable array is not one of
+    them.  QBP_TRUST_IDENTITY restores the fast path as an explicit choice; `forget` drops an entry; eviction
+    only drops the cache's reference."""
     from qldpc_amd import _lib, bp
     made = []
 
@@ -307,25 +310,48 @@ def test_decoder_cache_lookup_rules(monkeypatch):
             self.closed = True
 
     monkeypatch.setattr(_lib, "Decoder", Stub)
+    monkeypatch.setattr(bp, "TRUST_IDENTITY", False)
     bp.forget()
     try:
-        big = np.zeros((600, 600), np.float64)                    # 2.9 MB: identity + sampled checksum
+        big = np.zeros((600, 600), np.float64)                    # 2.9 MB
         big[np.arange(600), np.arange(600)] = 1
         d1 = bp.decoder_for(big)
-        assert bp.decoder_for(big) is d1 and len(made) == 1
-        bp.forget(big)
-        assert bp.decoder_for(big) is d1 and len(made) == 1       # same content: found again by its hash
-        big[5, 7] = 1
-        bp.forget(big)
-        assert bp.decoder_for(big) is not d1 and len(made) == 2
+        assert bp.decoder_for(big) is d1 and len(made) == 1       # same content: found by its hash
+        step = max(1, big.size // 65536)                           # the old sample grid: flat[::step]
+        assert step > 1
+        big.reshape(-1)[step * 1000 + 1] = 1                       # an edit OFF that grid, in place, no forget()
+        d2 = bp.decoder_for(big)
+        assert d2 is not d1 and len(made) == 2
+        # a read-only VIEW of a writeable array: its base can change under it -> hashed, and noticed
+        view = big[:]
+        view.setflags(write=False)
+        v1 = bp.decoder_for(view)
+        assert v1 is d2
+        big.reshape(-1)[step * 2000 + 1] = 1
+        assert bp.decoder_for(view) is not v1
+        # an array that cannot change: recognised by identity (no hash)
+        ro = np.eye(30, dtype=np.int64)
+        ro.setflags(write=False)
+        r1 = bp.decoder_for(ro)
+        calls = []
+        monkeypatch.setattr(bp, "_digest", lambda buf: calls.append(1) or b"x" * 16)
+        assert bp.decoder_for(ro) is r1 and not calls
+        monkeypatch.undo()
+        monkeypatch.setattr(_lib, "Decoder", Stub)
+        # the opt-in fast path: identity + sampled checksum for large writeable arrays (documented hazard)
+        monkeypatch.setattr(bp, "TRUST_IDENTITY", True)
+        big2 = np.zeros((600, 600), np.float64)
+        big2[np.arange(600), np.arange(600)] = 1
+        t1 = bp.decoder_for(big2)
+        big2.reshape(-1)[step * 1000 + 1] = 1                      # off the sample grid: NOT noticed in this mode
+        assert bp.decoder_for(big2) is t1
+        bp.forget(big2)                                            # ... until the caller says so
+        assert bp.decoder_for(big2) is not t1
+        monkeypatch.setattr(bp, "TRUST_IDENTITY", False)
         small = np.eye(20, dtype=np.int64)
         e1 = bp.decoder_for(small)
         small[0, 3] = 1                                           # in place: noticed without any call
         assert bp.decoder_for(small) is not e1
-        ro = np.eye(30, dtype=np.int64)
-        ro.setflags(write=False)
-        r1 = bp.decoder_for(ro)
-        assert bp.decoder_for(ro) is r1
         for k in range(20):                                       # more matrices than the cache holds
             bp.decoder_for(np.eye(40 + k, dtype=np.int64))
         assert not d1.closed and not e1.closed                    # evicted, never closed behind a holder's back
@@ -415,7 +441,7 @@ def test_performOSD_serves_the_driver_loop_from_one_batched_call(monkeypatch):
     llr = rng.normal(size=(B, n))
     hard = rng.integers(0, 2, (B, n)).astype(np.int8)
     conv = rng.random(B) < 0.4
-    monkeypatch.setattr(bp, "_LAST_BATCH", bp._LastBatch(dec, syn, llr, hard, conv))
+    bp._set_last_batch(bp._LastBatch(dec, syn, llr, hard, conv))
 
     def want(i, l=None, h=None):
         l = llr[i] if l is None else l
@@ -446,5 +472,18 @@ def test_performOSD_serves_the_driver_loop_from_one_batched_call(monkeypatch):
     monkeypatch.setattr(osd, "decoder_for", lambda H: other)  # another matrix: never from the cache
     assert np.array_equal(osd.performOSD(None, syn[k], llr[k], hard[k]), want(k)) and len(calls) == 6
     monkeypatch.setattr(osd, "decoder_for", lambda H: dec)
-    big = bp._LAST_BATCH_LIMIT // 8 // n + 1                  # LLR arrays above the limit are not kept alive
-    assert bp._LAST_BATCH.llr is llr and big * n * 8 > bp._LAST_BATCH_LIMIT
+    big = bp._LAST_BATCH_LIMIT // 8 // n + 1                  # LLR arrays above the limit are not remembered
+    assert bp._last_batch().llr is llr and big * n * 8 > bp._LAST_BATCH_LIMIT
+    # the record is the calling thread's own, and holds the returned arrays weakly
+    import threading
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(bp._last_batch()))
+    t.start(); t.join()
+    assert seen == [None]
+    lb = bp._last_batch()
+    del llr
+    import gc
+    gc.collect()
+    assert lb.llr is None                                     # nothing was kept alive
+    assert osd._from_last_batch(dec, syn[0].view(np.uint8), np.zeros(n), hard[0].view(np.uint8)) is None
+    assert bp._last_batch() is None                           # dead record dropped at the next look
