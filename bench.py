@@ -525,9 +525,9 @@ def main():
             costs = valu_issue_costs(local_rank)
         except Exception:
             costs = None
-    if full and world == 1 and costs is not None:
+    if full and world == 1:
         try:
-            others = other_config_legs(local_rank, costs, dec.info("num_cu"))
+            others = other_config_legs(local_rank, dec.info("num_cu"))
         except Exception as ex:
             others = {"error": f"{type(ex).__name__}: {ex}"}
 
@@ -584,153 +584,76 @@ def main():
         dist.destroy_process_group()
 
 
-def fused_symbol(variant, forced, one_bar, mc=False):
-    return (f"bp_fused_kernelILi6ELi3ELi{variant}ELb{int(mc)}ELb{int(forced)}ELi1024ELi1ELb{int(one_bar)}EE")
+PMC_LEGS = os.path.join(ROOT, "profiles", "r03_pmc_legs.json")       # tools/profile_r03.sh, tools/bench_legs.py --once
 
 
-def other_config_legs(device, costs, num_cu):
-    """The other BASELINE.json configurations on one GPU, each with the same issue-roofline accounting as the
-    headline: config 2 ([[72,12,6]], p = 0.01, 10 000 syndromes) and config 3 ([[144,12,12]], min-sum alpha 0.8 /
-    damping 0.7 / clip 25, 100 000 syndromes), early exit (reference semantics) and forced 50; the device-resident
-    Monte-Carlo loop of config 4 / 5 ([[288,12,18]]: sample + decode + classify, with and without OSD-0); the OSD-0
-    kernel alone.  Inputs resident in HBM, HIP events on the launch stream."""
+def other_config_legs(device, num_cu):
+    """The other BASELINE.json configurations on one GPU (tools/bench_legs.py defines the launches): config 2
+    ([[72,12,6]], p = 0.01, 10 000 syndromes) and config 3 ([[144,12,12]], min-sum alpha 0.8 / damping 0.7 / clip
+    25, 100 000 syndromes), early exit (reference semantics) and forced 50; the device-resident Monte-Carlo loop of
+    configs 4 / 5 ([[288,12,18]]: sample + decode + classify, with and without OSD-0); the OSD-0 kernel alone.
+    Timed live (HIP events on the launch stream, inputs resident in HBM).  Each leg's `roofline` prices the
+    vector instructions the HARDWARE counted for the very same launch (committed PMC summary: a static count of
+    the loop does not work for kernels whose iterations differ -- early exit -- or re-read kernel arguments) at
+    4 issue cycles each, 16 per v_rcp_f64, against SIMDs x time x the maximum shader clock."""
     import torch
-
-    from qldpc_amd import _lib, bp, codes, mc
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_legs
     dev = torch.device("cuda", device)
     st = torch.cuda.current_stream(dev)
-    legs = {}
-
-    def timed(fn, reps=5):
-        fn(); torch.cuda.synchronize(dev)
+    try:
+        pmc = json.load(open(PMC_LEGS))
+    except Exception:
+        pmc = {}
+    out = {}
+    for name, info, run, after in bench_legs.legs(device):
+        run(); torch.cuda.synchronize(dev)
         ms = []
-        for _ in range(reps):
+        for _ in range(5 if "config" in name else 3):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(st); fn(); b.record(st); torch.cuda.synchronize(dev)
+            a.record(st); run(); b.record(st); torch.cuda.synchronize(dev)
             ms.append(a.elapsed_time(b))
-        return float(np.median(ms))
-
-    for tag, name, p, B, variant, kw in (
-            ("config2", "[[72, 12, 6]]", 0.01, 10_000, _lib.SUM_PRODUCT, dict(alpha=1.0, damping=1.0, clip=20.0)),
-            ("config3", "[[144, 12, 12]]", 0.05, 100_000, _lib.MIN_SUM, dict(alpha=0.8, damping=0.7, clip=25.0))):
-        code = codes.load_code(name)
-        m, n = code.Hx.shape
-        E = int(code.Hx.sum())
-        g = torch.Generator(device=dev); g.manual_seed(5)
-        err = torch.rand((B, n), generator=g, device=dev) < p
-        Ht = torch.from_numpy(np.ascontiguousarray(code.Hx.T).astype(np.float32)).to(dev)
-        syn = (err.float() @ Ht).remainder_(2).to(torch.uint8).contiguous()
-        prior = torch.full((n,), float(np.log((1 - p) / p)), dtype=torch.float64, device=dev)
-        hard = torch.empty((B, n), dtype=torch.uint8, device=dev); conv = torch.empty((B,), dtype=torch.uint8, device=dev)
-        iters = torch.empty((B,), dtype=torch.int32, device=dev); llr = torch.empty((B, n), dtype=torch.float64, device=dev)
-        dec = bp.decoder_for(code.Hx, device=device)
-        leg = {"workload": f"{name} p={p} B={B} variant={int(variant)} " + " ".join(f"{k}={v}" for k, v in kw.items())}
-        for mode, flags in (("early_exit", 0), ("forced_50", _lib.FLAG_FORCE_FULL)):
-            def run():
-                dec.decode_device(syn.data_ptr(), prior.data_ptr(), B, MAX_ITER, variant, kw["alpha"], kw["damping"],
-                                  kw["clip"], flags, hard.data_ptr(), conv.data_ptr(), iters.data_ptr(),
-                                  llr.data_ptr(), st.cuda_stream)
-            ms = timed(run)
-            it_total = int(iters.sum(dtype=torch.int64).item()) + B if not flags else B * MAX_ITER
-            threads = dec.info("threads")
-            S, waves = max(1, threads // m), (threads + 63) // 64
-            one_bar = int(dec.info("one_barrier")) if flags else 0
-            r = {"value": B / ms * 1e3, "unit": "syndromes/s", "kernel_ms": ms,
-                 "mean_iterations": it_total / B, "converged_fraction": float(conv.float().mean().item())}
-            try:
-                roof = valu_roofline(_lib.LIB_PATH, fused_symbol(int(variant), bool(flags), one_bar), device,
-                                     it_total / S * waves, ms * 1e-3, num_cu, iters_per_trip=2 if one_bar else 1,
-                                     costs=costs)
-                r["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                      "frac_ideal_pricing", "flops_frac", "kernel",
-                                                      "valu_insts_per_wave_iteration")}
-                if not flags:
-                    r["roofline"]["note"] = ("per-iteration instructions only: the once-per-syndrome work (load, "
-                                             "emit, work fetch) is not in the count, so frac understates the issue "
-                                             "share at few iterations per syndrome")
-            except Exception as ex:
-                r["roofline"] = {"bound": "fp64_valu", "frac": None, "error": f"{type(ex).__name__}: {ex}"}
-            r["hbm_effective_GBps"] = algorithmic_bytes(E, m, n, it_total, B) / (ms * 1e-3) / 1e9
-            leg[mode] = r
-        legs[tag] = leg
-
-    # ---- Monte-Carlo loop and OSD-0 of [[288,12,18]] ----------------------------------------------------------
-    code = codes.load_code(CODE)
-    m, n = code.Hx.shape
-    dec = bp.decoder_for(code.Hx, device=device)
-    mcl = {}
-    for p, T, flags, tag in ((0.01, 4 << 20, 0, "p0.01"), (0.05, 1 << 20, 0, "p0.05"),
-                             (0.05, 1 << 20, _lib.FLAG_OSD0, "p0.05_osd0")):
-        prior = torch.from_numpy(mc.prior_of(p, n)).to(dev)
-        cnt = torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev)
-
-        def run():
-            for a in range(0, T, 1 << 20):
-                dec.mc_run_device(code.Lx, code.distance, p, prior.data_ptr(), a, min(a + (1 << 20), T),
-                                  cnt.data_ptr(), max_iter=MAX_ITER, flags=flags, stream=st.cuda_stream)
-        run(); torch.cuda.synchronize(dev); cnt.zero_()
-        ms = timed(run, reps=3)
-        c = (cnt // 3).cpu().numpy()
-        it_total = int(c[7] + c[0])
-        threads = dec.info("threads")
-        S, waves = max(1, threads // m), (threads + 63) // 64
-        r = {"value": T / ms * 1e3, "unit": "trials/s", "ms": ms, "ler": float(c[1] / c[0]),
-             "not_converged": float(c[6] / c[0]), "mean_iterations": it_total / T}
-        try:
-            roof = valu_roofline(_lib.LIB_PATH, fused_symbol(0, False, 0, mc=True), device, it_total / S * waves,
-                                 ms * 1e-3, num_cu, costs=costs)
-            r["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                  "frac_ideal_pricing", "flops_frac", "kernel",
-                                                  "valu_insts_per_wave_iteration")}
-            r["roofline"]["note"] = ("BP iterations only; sampling (Philox), classification and -- with OSD-0 -- the "
-                                     "second kernel are inside `ms` but not in the instruction count")
-        except Exception as ex:
-            r["roofline"] = {"bound": "fp64_valu", "frac": None, "error": f"{type(ex).__name__}: {ex}"}
-        mcl[tag] = r
-    legs["monte_carlo_288"] = mcl
-
-    # OSD-0 alone: BP failures of a p = 0.1 batch
-    B = 131072
-    p = 0.1
-    g = torch.Generator(device=dev); g.manual_seed(2)
-    err = torch.rand((B, n), generator=g, device=dev) < p
-    Ht = torch.from_numpy(np.ascontiguousarray(code.Hx.T).astype(np.float32)).to(dev)
-    syn = (err.float() @ Ht).remainder_(2).to(torch.uint8).contiguous()
-    prior = torch.full((n,), float(np.log((1 - p) / p)), dtype=torch.float64, device=dev)
-    hard = torch.empty((B, n), dtype=torch.uint8, device=dev); conv = torch.empty((B,), dtype=torch.uint8, device=dev)
-    iters = torch.empty((B,), dtype=torch.int32, device=dev); llr = torch.empty((B, n), dtype=torch.float64, device=dev)
-    sol = torch.empty((B, n), dtype=torch.uint8, device=dev)
-    dec.decode_device(syn.data_ptr(), prior.data_ptr(), B, MAX_ITER, 0, 1.0, 1.0, 20.0, 0, hard.data_ptr(),
-                      conv.data_ptr(), iters.data_ptr(), llr.data_ptr(), st.cuda_stream)
-    ms = timed(lambda: dec.osd0_device(syn.data_ptr(), llr.data_ptr(), hard.data_ptr(), B, sol.data_ptr(), st.cuda_stream),
-               reps=3)
-    ok = bool((((sol.float() @ Ht).remainder_(2).to(torch.uint8)) == syn).all())
-    osd = {"value": B / ms * 1e3, "unit": "OSD-0 solutions/s", "kernel_ms": ms, "B": B,
-           "all_solutions_reproduce_their_syndrome": ok}
-    pm = committed_pmc("osd0_kernel")
-    if pm:
-        c = {k: v["last"] for k, v in pm["counters"].items()}
-        wc = c.get("SQ_WAVE_CYCLES")
-        if wc:
-            # (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count in the same unit: shares are unit-free)
-            osd["roofline"] = {
-                "bound": "lds_latency", "achieved": B / ms * 1e3, "peak": None, "unit": "OSD-0 solutions/s",
-                "frac": None, "traffic": None,
-                "pmc_file": os.path.relpath(PMC_SUMMARY, ROOT),
-                "wave_cycle_shares": {"waiting (s_waitcnt / barrier)": c.get("SQ_WAIT_ANY", 0) / wc,
-                                      "issue stalled": c.get("SQ_WAIT_INST_ANY", 0) / wc,
-                                      "issuing any instruction": c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
-                                      "issuing LDS": c.get("SQ_ACTIVE_INST_LDS", 0) / wc,
-                                      "issuing VALU": c.get("SQ_ACTIVE_INST_VALU", 0) / wc},
-                "lds_bank_conflict_share": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
-                                            if c.get("SQ_LDS_IDX_ACTIVE") else None),
-                "insts_per_solution": {"valu": c.get("SQ_INSTS_VALU", 0) / B, "lds": c.get("SQ_INSTS_LDS", 0) / B,
-                                       "salu": c.get("SQ_INSTS_SALU", 0) / B},
-                "note": "one wavefront per syndrome: Gauss-Jordan elimination over bit-packed rows in LDS is a chain "
-                        "of dependent LDS round trips (pivot search, row XOR); the counters say where the wave "
-                        "cycles go (DESIGN.md section 4)"}
-    legs["osd0_288"] = osd
-    return legs
+        r = dict(info, **after())
+        r["kernel_ms"] = float(np.median(ms))
+        r["value"] = r["units"] / r["kernel_ms"] * 1e3
+        if "iterations_total" in r:
+            r["mean_iterations"] = r["iterations_total"] / r["units"]
+            if "E" in info:
+                r["hbm_effective_GBps"] = algorithmic_bytes(info["E"], info["m"], info["n"], r["iterations_total"],
+                                                            r["units"]) / (r["kernel_ms"] * 1e-3) / 1e9
+        disp = pmc.get(name)
+        if disp and name == "osd0_288":
+            disp = disp[-1:]                    # (its first dispatch is the BP decode that makes the inputs: untimed)
+        if disp:
+            avail = num_cu * 4 * r["kernel_ms"] * 1e-3 * MAX_CLOCK_HZ
+            valu = sum(d["counters"].get("SQ_INSTS_VALU", 0.0) for d in disp)
+            trans = sum(d["counters"].get("SQ_INSTS_VALU_TRANS_F64", 0.0) for d in disp)
+            wc = sum(d["counters"].get("SQ_WAVE_CYCLES", 0.0) for d in disp)
+            main = disp[-1]["counters"]
+            roof = {"bound": "fp64_valu" if "osd0" not in name else "latency (dependent LDS / scalar chains)",
+                    "achieved": valu * 64 / (r["kernel_ms"] * 1e-3) / 1e12,
+                    "peak": num_cu * 4 * 16 * MAX_CLOCK_HZ / 1e12, "unit": "Tlane-instr/s",
+                    "frac": ((valu - trans) * 4.0 + trans * 16.0) / avail, "traffic": None,
+                    "pricing": "PMC instruction count of this launch x 4 issue cycles (16 per v_rcp_f64)",
+                    "pmc_file": os.path.relpath(PMC_LEGS, ROOT), "kernels": [d["kernel"] for d in disp],
+                    "SQ_INSTS_VALU": valu,
+                    "pmc_kernel_ms": [next(iter(d["duration_ns"].values())) / 1e6 if d["duration_ns"] else None for d in disp]}
+            if main.get("SQ_WAVE_CYCLES"):
+                w = main["SQ_WAVE_CYCLES"]
+                roof["wave_cycle_shares_last_kernel"] = {
+                    "waiting (s_waitcnt / barrier)": main.get("SQ_WAIT_ANY", 0) / w,
+                    "issue stalled": main.get("SQ_WAIT_INST_ANY", 0) / w,
+                    "issuing any instruction": main.get("SQ_ACTIVE_INST_ANY", 0) / w,
+                    "issuing VALU": main.get("SQ_ACTIVE_INST_VALU", 0) / w,
+                    "issuing LDS": main.get("SQ_ACTIVE_INST_LDS", 0) / w}
+                if main.get("SQ_LDS_IDX_ACTIVE"):
+                    roof["lds_bank_conflict_share"] = main.get("SQ_LDS_BANK_CONFLICT", 0) / main["SQ_LDS_IDX_ACTIVE"]
+            r["roofline"] = roof
+        else:
+            r["roofline"] = {"bound": "fp64_valu", "frac": None, "traffic": None,
+                             "error": f"no entry for {name} in {os.path.relpath(PMC_LEGS, ROOT)}"}
+        out[name] = r
+    return out
 
 
 def dropin_leg(code, device, p=0.05, batch=5000, batches=4, max_iter=150):

@@ -132,16 +132,22 @@ def demangle(sym):
 
 def loop_mix(insts):
     """VALU instructions per execution of the main loop's always-executed part, by class."""
-    # the main loop: of all backward branches, the one whose span holds the most FP64 arithmetic;
-    # among equals the tightest (out-of-line cold blocks behind the loop jump back over it too)
+    # the main loop: the phase loop of the kernel is the one that synchronises -- of all backward branches whose
+    # span contains a workgroup barrier (inner loops -- sampling, emission, rare paths -- hold none), the one
+    # whose span holds the most FP64 arithmetic, among equals the tightest (the compiler rotates the phase loop
+    # into a steady-state loop and an outer path taken once per syndrome; out-of-line cold blocks behind the
+    # loop jump back over it too); kernels without barriers (the streaming kernel): the same without the
+    # barrier condition
     addrs = [a for a, m, o, t in insts if m.startswith("v_") and "_f64" in m]
+    bars = [a for a, m, o, t in insts if m.startswith("s_barrier")]
     back = []
     for a, m, o, t in insts:
         if t is not None and t <= a:
-            back.append((sum(1 for x in addrs if t <= x <= a), -(a - t), t, a))
+            nbar = sum(1 for x in bars if t <= x <= a)
+            back.append((1 if nbar else 0, sum(1 for x in addrs if t <= x <= a), -(a - t), t, a))
     if not back:
         return None
-    _, _, lo, hi = max(back)
+    _, _, _, lo, hi = max(back)
     body = [(a, m, o, t) for a, m, o, t in insts if lo <= a <= hi]
     # if-regions from forward conditional branches inside the loop: (start, end) half-open
     # (a branch to an out-of-line block behind the loop guards everything up to the loop's end)
