@@ -241,7 +241,7 @@ def test_bench_accounting_and_committed_line():
     # [[288,12,18]]: E = 864, m = 144, n = 288 -> 27 648 B per iteration, 2 741 B of I/O per syndrome
     assert bench.algorithmic_bytes(864, 144, 288, 1, 0) == 27648
     assert bench.algorithmic_bytes(864, 144, 288, 50, 1) == 1382400 + 2741
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_1gpu.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_1gpu.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline",
                 "hbm_effective", "early_exit", "stress_p010", "sustained", "dropin_api"):
@@ -256,6 +256,16 @@ def test_bench_accounting_and_committed_line():
     available = r["simds"] * r["kernel_ms"] * 1e-3 * r["max_clock_GHz"] * 1e9
     assert abs(r["frac"] - needed / available) < 1e-9
     assert sum(r["valu_by_class"].values()) == r["valu_insts_per_wave_iteration"]
+    # round 3: the same fraction with ideal issue costs, the useful-flop share of the 78.6 TFLOP/s vector peak,
+    # the HBM bytes per launch and the hardware's own instruction count from the committed PMC summary
+    assert 0.0 < r["frac_ideal_pricing"] <= r["frac"] and 0.0 < r["flops_frac"] < r["frac"]
+    assert r["traffic"] and abs(r["traffic"] / (125000 * 2741) - 1.0) < 0.15      # = the syndrome / LLR I/O
+    assert r["pmc"]["file"] == "profiles/r03_pmc_summary.json"
+    assert abs(r["pmc"]["static_count_over_pmc_count"] - 1.0) < 0.05
+    for leg in ("config2_early_exit", "config2_forced_50", "config3_early_exit", "config3_forced_50",
+                "mc288_p0.01", "mc288_p0.05", "mc288_p0.05_osd0", "osd0_288"):
+        lr = line["other_configs"][leg]["roofline"]
+        assert lr["frac"] is not None and 0.0 < lr["frac"] <= 1.0 and lr["pmc_file"] == "profiles/r03_pmc_legs.json"
     assert line["hbm_effective"]["unit"] == "GB/s"       # the north star's yardstick, kept beside it
     assert line["sustained"]["seconds"] >= 9.5 and 0.9 < line["sustained"]["ratio_to_headline"] < 1.1
     assert 0.95 < line["stress_p010"]["ratio_to_headline_kernel_ms"] < 1.05
@@ -265,6 +275,28 @@ def test_bench_accounting_and_committed_line():
     assert line["value"] > 1e6            # the north star's floor
     two = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_2rank_gloo_rehearsal.json")))
     assert two["n_gpus"] == 2 and two["multi_gpu"]["n_ranks_seen"] == 2
+
+
+def test_static_instruction_count_of_the_built_library_matches_the_committed_pmc_count(lib):
+    """The headline roofline prices a STATIC count of the kernel's loop (tools/valu_mix.py on the library as built).
+    It must stay within a few percent of what the hardware counted for the same kernel (SQ_INSTS_VALU of
+    profiles/r03_pmc_summary.json): a compiler or source change that moves code across the tool's cold-region
+    markers shows up here, not as a silently shifted efficiency figure."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_mix
+    res = valu_mix.analyse(_lib.LIB_PATH, ["bp_fused_kernelILi6ELi3ELi0ELb0ELb1ELi1024ELi1ELb1EE"])
+    assert len(res) == 1
+    mix = next(iter(res.values()))
+    static = mix["valu_total"] / 2                      # the one-barrier loop holds two BP iterations
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+    k = next(v for name, v in pmc.items() if "bp_fused_kernel<6, 3, 0, false, true, 1024, 1, true>" in name)
+    wave_iterations = 125000 * 50 / 7 * 16              # the bench launch: 7 slots per 16-wave workgroup
+    counted = k["counters"]["SQ_INSTS_VALU"]["last"] / wave_iterations
+    assert abs(static / counted - 1.0) < 0.05, (static, counted)
+    per_class = {c: n / 2 for c, n in mix["valu_by_class"].items()}
+    for cls, ctr in (("fma_f64", "SQ_INSTS_VALU_FMA_F64"), ("add_f64", "SQ_INSTS_VALU_ADD_F64"),
+                     ("mul_f64", "SQ_INSTS_VALU_MUL_F64"), ("trans_f64", "SQ_INSTS_VALU_TRANS_F64")):
+        assert abs(per_class[cls] - k["counters"][ctr]["last"] / wave_iterations) < 0.51, cls
 
 
 def test_self_launch_command_and_supervisor(tmp_path):
