@@ -310,19 +310,20 @@ class _LastBatch:
     batched OSD launch: see qldpc_amd/osd.py.
 
     Lifetime: the record is per THREAD (a thread pool's workers do not overwrite each other's
-    batch); it holds the returned LLR / hard arrays only WEAKLY -- rows are recognised by address, which is
-    only meaningful while the caller still holds the arrays; once they are gone the record is dead and
-    nothing is kept alive -- plus the syndromes (B x m bytes) and, once the first OSD call arrives, its own
-    gathered copies of the failing rows and their solutions; it is dropped when every failing row has been
+    batch); it holds the returned LLR array (8 n bytes per syndrome, the bulk) only WEAKLY -- rows are recognised
+    by their address in it, which is only meaningful while the caller still holds the array; once it is gone the
+    record is dead and nothing big is kept alive -- plus the hard decisions and the syndromes (n + m bytes per
+    syndrome) and, once the first OSD call arrives, its own gathered copies of the failing rows and their
+    solutions; it is dropped when every failing row has been
     served, at the next batch call of the thread, or never created with QBP_NO_LAST_BATCH=1
     (qldpc_amd.bp.REMEMBER_LAST_BATCH = False)."""
-    __slots__ = ("dec", "syn", "llr_ref", "hard_ref", "conv", "addr", "rowbytes", "rows", "pos", "inputs",
+    __slots__ = ("dec", "syn", "llr_ref", "hard", "conv", "addr", "rowbytes", "rows", "pos", "inputs",
                  "solutions", "lock", "served", "n_fail")
 
     def __init__(self, dec, syn, llr, hard, conv):
         import weakref
         self.dec, self.syn, self.conv = dec, syn, conv.copy()
-        self.llr_ref, self.hard_ref = weakref.ref(llr), weakref.ref(hard)
+        self.llr_ref, self.hard = weakref.ref(llr), hard
         self.addr = llr.__array_interface__["data"][0]
         self.rowbytes, self.rows = llr.strides[0], llr.shape[0]
         self.pos = self.inputs = self.solutions = None
@@ -332,10 +333,6 @@ class _LastBatch:
     @property
     def llr(self):
         return self.llr_ref()
-
-    @property
-    def hard(self):
-        return self.hard_ref()
 
 
 REMEMBER_LAST_BATCH = os.environ.get("QBP_NO_LAST_BATCH", "0") in ("0", "")
