@@ -177,6 +177,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
         for (int j = 0; j < D; ++j) {
             t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);
             prod = (j == 0) ? t[0] : prod * t[j];
+            QBP_EDGE_FENCE();
         }
         // (t_safe, :122: |t| <= 1, so a product of at least 1e-15 has no factor below it -- one wave-uniform
         // test instead of D compares and 2 D selects, as in the on-chip kernel)
@@ -189,6 +190,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
             const double ts = t[j];
             const double x = check_message<VARIANT>(div_nr(prod, ts), sbit, np_tab);     // :123-126
             r[j] = (VARIANT == 1 && scale) ? x * alpha : x;
+            QBP_EDGE_FENCE();
         }
     }
 }

@@ -278,7 +278,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
             double t[DC];
             double prod;
 #pragma unroll
-            for (int j = 0; j < DC; ++j) t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);     // np.tanh(Q * 0.5), :114
+            for (int j = 0; j < DC; ++j) {
+                t[j] = tanh_half_msg<VARIANT>(q[j], np_tab);     // np.tanh(Q * 0.5), :114
+                if constexpr (DC > 6) QBP_EDGE_FENCE();
+            }
 #pragma unroll
             for (int j = 0; j < DC; ++j) prod = (j == 0) ? t[0] : prod * t[j];     // np.prod, ascending column
             // t_safe = where(|t| < 1e-15, 1e-15, t) (:122).  |t| <= 1, so a row whose product is at least
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES_PER_SIMD) void bp_fused_kern
                     // quotient is at least 1e-15 in magnitude (check_message: NORMAL)
                     const double r = check_message<VARIANT, true>(div_nr(prod, t[j]), sb, np_tab);     // :123-126
                     put(j, VARIANT == 1 ? r * P.alpha : r);
+                    if constexpr (DC > 6) QBP_EDGE_FENCE();
                 }
             }
         }

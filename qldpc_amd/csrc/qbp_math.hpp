@@ -457,6 +457,16 @@ QBP_HD double clip_unit(double x)
     return __builtin_fmin(__builtin_fmax(x, -C), C);
 }
 
+// Scheduling fence between the messages of a wide row: the compiler otherwise overlaps all of a row's table-driven
+// evaluations, whose live values then exceed the register budget of the wide builds (general-H kernel on
+// 2592 x 7776, messages partly in L2: 1.33e5 -> 1.47e5 syndromes/s, 208 -> 184 spilled bytes; no change elsewhere:
+// profiles/r03_ab_math.txt, block 6).  -DQBP_NO_EDGE_FENCES for A/B.
+#if defined(QBP_DEVICE_BITS) && !defined(QBP_NO_EDGE_FENCES)
+#define QBP_EDGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define QBP_EDGE_FENCE() ((void)0)
+#endif
+
 // The tail of the check update for one edge (beliefPropagation.py:125-126):
 //     R = 2.0 * np.arctanh(np.clip(x * syndrome_sign, -0.9999999, 0.9999999)),   x = prod / t_safe.
 // Multiplying by +-1, clipping to a symmetric interval and np.arctanh (which works on |y| and multiplies by
