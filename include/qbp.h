@@ -250,8 +250,11 @@ enum {
                                          its messages, which depend on the priors and the syndrome bit only; A/B, tests) */
     QBP_OPT_FORCED_TWO_BARRIERS = 11, /* 1 = QBP_FLAG_FORCE_FULL launches keep both barriers of the iteration
                                          (default: one barrier, two copies of the messages in LDS; A/B, tests) */
-    QBP_OPT_OSD_BIG = 7,         /* 1 = OSD-0 through the workgroup-per-syndrome kernel (matrix in
-                                    global memory) even where the one-wavefront kernel fits (tests) */
+    QBP_OPT_OSD_BIG = 7,         /* tests: OSD-0 through a workgroup-per-syndrome kernel (matrix in global memory) even
+                                    where the one-wavefront kernel fits.  1 = the kernel such matrices get (eight
+                                    pivots at a time up to 8192 rows), 2 = the one-pivot-at-a-time kernel (larger
+                                    matrices), 3 = as 1 with a first sweep over too few sorted columns, so that
+                                    the full-width second sweep runs */
     QBP_OPT_DEBUG_THROW = 99,    /* tests (null handle allowed): raise inside the entry point -- 1 std::bad_alloc
                                     (-> QBP_E_NOMEM), 2 std::runtime_error, 3 a non-standard exception
                                     (-> QBP_E_INVALID): no exception crosses the ABI */

@@ -152,6 +152,7 @@ struct qbp_handle {
     size_t stage_bytes = 0;
     // OSD-0
     bool osd_ok = false;            // fits the one-wavefront kernel (matrix rows in LDS)
+    int opt_osd_big = 0;            // QBP_OPT_OSD_BIG
     bool osd_big_ready = false;     // tables of the workgroup-per-syndrome kernel built (lazily)
     int osd_W = 0, osd_NP = 0, osd_lds = 0, osd_rank = 0;
     DevBuf<uint32_t> d_osd_At;
@@ -1317,13 +1318,46 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
     O.row_ptr = h->d_row_ptr.p; O.col_idx = h->d_col_idx.p;
     if (!h->osd_ok) {
         // matrices whose rows do not fit 64 KiB of LDS: one workgroup per syndrome, working copy of
-        // [H | s] in a global workspace (qbp_osd.hpp, osd0_big_kernel)
+        // [H | s] in a global workspace (qbp_osd.hpp: osd0_blocked_kernel; osd0_big_kernel beyond 8192 rows)
         int rc = osd_big_prepare(h);
         if (rc) return rc;
         O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
         const size_t m = h->m, n = h->n, RS = (size_t)h->osd_W + 1, NP = (size_t)h->osd_NP;
-        const int grid = (int)std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 2));
         qbp::OsdBigWorkspace Wk{};
+        // -- eight pivots at a time
+        const size_t wc_max = (n + 63) / 64 + 1;
+        const size_t LDS_MAX = 160 * 1024 - 64;                      // (static __shared__ of the kernel: 40 bytes)
+        const size_t qs = 8 * wc_max * 8;
+        const size_t want_table = std::min<size_t>(96 * 1024, 256 * wc_max * 8);
+        size_t region0 = std::max(want_table, NP * 8), lds = region0 + qs + NP * 4 + ((n + 15) & ~(size_t)15);
+        Wk.keys_in_lds = 1;
+        if (lds > LDS_MAX) { Wk.keys_in_lds = 0; region0 = want_table; lds = region0 + qs; }
+        const bool blocked = h->opt_osd_big != 2 && m <= 8192 && lds <= LDS_MAX && 2 * wc_max * 8 <= want_table;
+        if (blocked) {
+            const int grid = (int)std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu));
+            Wk.wc_max = (int)wc_max;
+            // first sweep: the 2048 least reliable columns (a sweep ends where no unpivoted row has a syndrome
+            // bit left -- after some 200 columns on the BP failures of the space-time matrices in the tests,
+            // 1632 at most)
+            Wk.k_first = h->opt_osd_big == 3 ? 24 : (int)std::min<size_t>(n, 2048);
+            if (lds + m * 4 <= LDS_MAX && h->opt_osd_big != 3) { Wk.lds_act = (int)lds; lds += m * 4; }
+            HIP_TRY(h->d_osd_piv.reserve(2));
+            HIP_TRY(hipMemsetAsync(h->d_osd_piv.p, 0, 8, s));
+            Wk.next = reinterpret_cast<unsigned long long*>(h->d_osd_piv.p);
+            Wk.lds_region0 = (int)region0; Wk.lds_table = (int)want_table;
+            HIP_TRY(h->d_osd_At.reserve((size_t)grid * wc_max * m * 2));
+            if (!Wk.keys_in_lds) {
+                HIP_TRY(h->d_osd_sol.reserve((size_t)grid * n));
+                HIP_TRY(h->d_osd_keys.reserve((size_t)grid * NP));
+                HIP_TRY(h->d_osd_idx.reserve((size_t)grid * NP));
+            }
+            Wk.At = h->d_osd_At.p; Wk.sol = h->d_osd_sol.p; Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
+            const int rpt = m <= 1024 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 4 : 8;
+            HIP_TRY(qbp::launch_osd_blocked(rpt, (unsigned)grid, lds, O, Wk, s));
+            return QBP_OK;
+        }
+        // -- one pivot at a time
+        const int grid = (int)std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 2));
         Wk.keys_in_lds = NP * 12 <= (size_t)96 * 1024 ? 1 : 0;
         HIP_TRY(h->d_osd_At.reserve((size_t)grid * RS * m));
         HIP_TRY(h->d_osd_piv.reserve((size_t)grid * m));
@@ -1334,8 +1368,8 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
         }
         Wk.At = h->d_osd_At.p; Wk.pivcol = h->d_osd_piv.p; Wk.sol = h->d_osd_sol.p;
         Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
-        const size_t lds = Wk.keys_in_lds ? NP * 12 : 0;
-        HIP_TRY(qbp::launch_osd_big((unsigned)grid, lds, O, Wk, s));
+        const size_t lds1 = Wk.keys_in_lds ? NP * 12 : 0;
+        HIP_TRY(qbp::launch_osd_big((unsigned)grid, lds1, O, Wk, s));
         return QBP_OK;
     }
     O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
@@ -1592,6 +1626,8 @@ try {
         case QBP_OPT_FORCED_TWO_BARRIERS:
             h->opt_forced_two_barriers = value != 0; return QBP_OK;
         case QBP_OPT_OSD_BIG:
+            if (value < 0 || value > 3) return fail(QBP_E_INVALID, "OSD kernel selector out of range");
+            h->opt_osd_big = (int)value;
             if (value != 0) { h->osd_ok = false; }
             else {
                 const size_t lds = qbp::osd_lds_bytes(h->m, h->n, h->osd_W, h->osd_NP);

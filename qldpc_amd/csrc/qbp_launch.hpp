@@ -51,6 +51,8 @@ hipError_t launch_stream(int variant, unsigned grid, const StreamParams& P, cons
 // qbp_tu_osd.hip
 hipError_t launch_osd_small(int words_per_row, unsigned grid, size_t lds, const OsdParams& O, hipStream_t s);
 hipError_t launch_osd_big(unsigned grid, size_t lds, const OsdParams& O, const OsdBigWorkspace& Wk, hipStream_t s);
+hipError_t launch_osd_blocked(int rows_per_thread, unsigned grid, size_t lds, const OsdParams& O,
+                              const OsdBigWorkspace& Wk, hipStream_t s);
 hipError_t launch_hist_minmax(int grid, const double* x, long long count, double* part, hipStream_t s);
 hipError_t launch_hist_bin(int grid, size_t lds, const double* msg, const uint8_t* errors, const int32_t* col_idx,
                            long long B, int E, int n, const double* edges, int bins, unsigned long long* hist,

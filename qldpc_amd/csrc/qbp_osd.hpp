@@ -116,11 +116,13 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
         }
         // ---- 2. A = [H | residual syndrome], residual = syndrome + hard @ H.T  OSD.py:7-8
         // (A overwrites the sort keys: every lane passed the sort's last barrier)
-        for (int r = lane; r < m; r += 64) {
+        unsigned sb = 0;                             // bit i: reduced syndrome bit of row lane + 64 i
+        for (int r = lane, i = 0; r < m; r += 64, ++i) {
             for (int w = 0; w < W; ++w) A[r * RS + w] = P.hbits[r * W + w];
             unsigned par = syn[r] & 1u;
             for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) par ^= sol[P.col_idx[e]];
             A[r * RS + W] = par;
+            sb |= par << i;
             pivcol[r] = -1;
         }
         __syncthreads();
@@ -130,7 +132,13 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
         // into registers when it fits (WW = words per row incl. the syndrome word, compile time).
         int rank = 0;
         unsigned used = 0;                           // bit i: row lane + 64 i already serves as a pivot row
-        for (int k = 0; k < n && rank < P.rank; ++k) {   // :42-43 stops at m rows; rank(H) <= m
+        // The sweep ends at the rank of H (:42-43 stops at m rows; rank(H) <= m) -- or as soon as no row without
+        // a pivot has a 1 left in the syndrome column: every pivot found from there on would be chosen with a
+        // reduced syndrome bit of 0, XOR nothing into the syndrome bits of the rows above it and put a 0 at its
+        // own column, so the solution is already what the full sweep leaves.  (The residual syndrome of a BP
+        // failure is light: the sweep typically ends after a small part of the columns.)
+        for (int k = 0; k < n && rank < P.rank; ++k) {
+            if (!__ballot((sb & ~used) != 0u)) break;
             const int c = idx[k];
             const int wi = c >> 5;
             const uint32_t bit = 1u << (c & 31);
@@ -154,12 +162,15 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
                     if (r != p && ((has >> i) & 1u)) {
 #pragma unroll
                         for (int w = 0; w < WW; ++w) A[r * RS + w] ^= prow[w];              // :63-68
+                        sb ^= (prow[WW - 1] & 1u) << i;
                     }
                 }
             } else {
+                const unsigned ps = A[p * RS + W] & 1u;
                 for (int r = lane, i = 0; r < m; r += 64, ++i) {
                     if (r != p && ((has >> i) & 1u)) {
                         for (int w = 0; w <= W; ++w) A[r * RS + w] ^= A[p * RS + w];        // :63-68
+                        sb ^= ps << i;
                     }
                 }
             }
@@ -234,6 +245,13 @@ struct OsdBigWorkspace {
     unsigned long long* keys;       // [grid][NP]   (only when the keys do not fit LDS)
     int32_t* idx;                   // [grid][NP]
     int keys_in_lds;
+    // osd0_blocked_kernel only (At: 64-bit words there, [grid][wc_max * m])
+    int wc_max;                     // word planes of a full-width working copy: (n + 63) / 64 + 1
+    int k_first;                    // sorted columns the first sweep keeps
+    int lds_region0, lds_table;     // bytes: {keys | pos | table} region; the part of it the table may use
+    int lds_act;                    // byte offset of the list of rows a block updates (m words), 0: none -- every
+                                    // thread then updates its own rows
+    unsigned long long* next;       // work counter (zero at launch): syndromes are handed out one at a time
 };
 
 #ifdef QBP_DEFINE_KERNELS   /* non-template kernel: defined in its translation unit only */
@@ -372,6 +390,383 @@ __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const 
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same OSD-0, eight pivots at a time ("four Russians" blocking of the Gauss-Jordan sweep): the kernel
+// for space-time / circuit-level matrices of up to 8192 rows.  One workgroup of 1024 threads per syndrome.
+//
+//  * A sweep ends as soon as no row without a pivot has a syndrome bit left (see osd0_kernel): after some 200
+//    of the 5184 / 7776 columns on the BP failures of the tests' space-time matrices, 1632 at most.  So only
+//    the first K = 1024 columns in reliability order are kept: the working copy holds H[:, order[:K]] in
+//    SORTED column order, built from the CSR through the inverse permutation: 64-bit words, transposed
+//    (word w of row r at At[w * m + r]: a wavefront's rows are consecutive), the residual syndrome bit in a
+//    word plane of its own behind them.  A sweep that runs out of columns before it may end starts over with
+//    4 K columns, then 16 K, ... n (tests force that path: QBP_OPT_OSD_BIG = 3 begins with K = 24).
+//  * Sorted order means column k is never looked at again once it is passed: row operations only touch the
+//    word planes from k / 64 on.
+//  * A block is T <= 8 neighbouring columns inside one word.  Every thread keeps the T bits of its rows in a
+//    register (a "byte"), and the sweep over the block's columns works on those bytes alone: per column one
+//    LDS atomicMin (first not-yet-used row with the bit: decoding/OSD.py:46-50) and ONE barrier; a row that
+//    has the bit XORs the pivot's byte into its own and notes which of the block's pivot rows it has to take
+//    (D, a T-bit set over the pivot rows AS THEY WERE WHEN THE BLOCK BEGAN; a pivot row's own D at the moment
+//    it is chosen travels with it through the atomicMin word).  Then the block's pivot rows go to LDS, all
+//    2^T XOR combinations of them are tabulated there, and every row of the matrix is updated ONCE:
+//    row ^= table[D].  Global traffic per block: one read-modify-write of the live word planes instead of
+//    one per pivot.
+//  * Same pivot columns as the row-at-a-time kernels (the greedy basis in reliability order does not depend
+//    on the blocking), hence the same solutions: tests/test_gpu_osd.py compares all three kernels.
+#ifdef QBP_OSD_TIMING   /* tools/osd_phases.py: cycles of thread 0 per phase, summed over workgroups */
+__device__ unsigned long long g_osd_timing[8];
+#define OSD_T0() long long t_prev = clock64(); unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define OSD_T(i) do { const long long t_now = clock64(); t_acc[i] += (unsigned long long)(t_now - t_prev); t_prev = t_now; } while (0)
+#define OSD_TEND() do { if (threadIdx.x == 0) for (int q = 0; q < 8; ++q) atomicAdd(&g_osd_timing[q], t_acc[q]); } while (0)
+__device__ unsigned long long g_osd_stat[8];   /* blocks, active rows, live words of active rows, columns swept */
+#define OSD_STAT(i, v) atomicAdd(&g_osd_stat[i], (unsigned long long)(v))
+#define OSD_SYNC() __syncthreads()
+#else
+#define OSD_STAT(i, v) do {} while (0)
+#define OSD_SYNC() do {} while (0)
+#define OSD_T0() do {} while (0)
+#define OSD_T(i) do {} while (0)
+#define OSD_TEND() do {} while (0)
+#endif
+
+template <int RPT>
+__global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, const OsdBigWorkspace Wk)
+{
+    extern __shared__ double osd_smem[];
+    __shared__ unsigned s_piv[3];
+    __shared__ unsigned s_nact[2];
+    __shared__ unsigned long long s_lm, s_item;
+    __shared__ int s_ew, s_df, s_bad;
+    typedef unsigned long long u64;
+    const int tid = threadIdx.x, nt = 1024;
+    const int m = P.m, n = P.n, NP = P.NP;
+    char* const lds = reinterpret_cast<char*>(osd_smem);
+    unsigned* const act = Wk.lds_act ? reinterpret_cast<unsigned*>(lds + Wk.lds_act) : nullptr;
+    u64* const table = reinterpret_cast<u64*>(lds);                        // region 0: keys -> pos -> table
+    u64* const Qs = reinterpret_cast<u64*>(lds + Wk.lds_region0);          // [8][wc_max]
+    u64* keys;
+    int *idx, *pos;
+    uint8_t* sol;
+    if (Wk.keys_in_lds) {
+        keys = reinterpret_cast<u64*>(lds);
+        pos = reinterpret_cast<int*>(lds);
+        idx = reinterpret_cast<int*>(lds + Wk.lds_region0 + (size_t)8 * Wk.wc_max * 8);
+        sol = reinterpret_cast<uint8_t*>(idx + NP);
+    } else {
+        keys = Wk.keys + (size_t)blockIdx.x * NP;
+        pos = reinterpret_cast<int*>(keys);
+        idx = Wk.idx + (size_t)blockIdx.x * NP;
+        sol = Wk.sol + (size_t)blockIdx.x * n;
+    }
+    u64* const At = reinterpret_cast<u64*>(Wk.At) + (size_t)blockIdx.x * Wk.wc_max * m;
+    OSD_T0();
+    if (tid < 3) s_piv[tid] = ~0u;
+    if (tid < 2) s_nact[tid] = 0u;
+    unsigned col_ctr = 0;                     // columns swept so far: slot col_ctr % 3 of s_piv is the live one
+    unsigned blk_ctr = 0;                     // blocks with pivots so far: s_nact[blk_ctr & 1] counts this one's rows
+    __syncthreads();
+
+    const long long total = P.count_ptr ? *P.count_ptr : P.count;
+    // (syndromes one at a time from a counter: a sweep takes anything between 0.3 and 20 ms)
+    for (;;) {
+        if (tid == 0) s_item = atomicAdd(Wk.next, 1ull);
+        __syncthreads();
+        const long long item = (long long)s_item;
+        if (item >= total) break;
+        const long long rec = P.list ? P.list[item] : item;
+        const double* llr = P.llr + rec * n;
+        const uint8_t* hard = P.hard + rec * n;
+        const uint8_t* syn = P.syndromes + rec * m;
+        // ---- 1. ordering = argsort(|llr|), ties by column index                    OSD.py:10-11
+        for (int i = tid; i < NP; i += nt) {
+            keys[i] = i < n ? osd_order_key(llr[i]) : ~0ull;
+            idx[i] = i;
+        }
+        for (int i = tid; i < n; i += nt) sol[i] = hard[i] & 1u;
+        __syncthreads();
+        for (int k = 2; k <= NP; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < NP / 2; t += nt) {
+                    const int lo = ((t / j) * (2 * j)) + (t % j);
+                    const int hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const u64 ka = keys[lo], kb = keys[hi];
+                    const int ia = idx[lo], ib = idx[hi];
+                    if (osd_less(kb, ib, ka, ia) == up) {
+                        keys[lo] = kb; keys[hi] = ka; idx[lo] = ib; idx[hi] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        OSD_T(0);
+        int pc[RPT];                          // pivot column (original index) of this thread's rows, -1: none yet
+        int Wc = 0;
+        unsigned sb = 0;                      // bit i: reduced syndrome bit of row tid + i * nt
+        for (int K = Wk.k_first < n ? Wk.k_first : n;; K = K < n / 4 ? 4 * K : n) {
+            Wc = ((K + 63) >> 6) + 1;         // word planes: K sorted columns, then the syndrome bit
+            // ---- 2. A = [H[:, order[:K]] | residual syndrome]                       OSD.py:7-11
+            for (int k = tid; k < n; k += nt) pos[idx[k]] = k;
+            __syncthreads();
+            sb = 0;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = tid + i * nt;
+                pc[i] = -1;
+                if (r >= m) continue;
+                for (int w = 0; w < Wc - 1; ++w) At[(size_t)w * m + r] = 0ull;
+                unsigned par = syn[r] & 1u;
+                for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) {
+                    const int c = P.col_idx[e];
+                    par ^= sol[c];
+                    const int k = pos[c];
+                    if (k < K) At[(size_t)(k >> 6) * m + r] |= 1ull << (k & 63);
+                }
+                At[(size_t)(Wc - 1) * m + r] = par;
+                sb |= par << i;
+            }
+            __syncthreads();                  // (pos is dead from here on: the table takes its place)
+            OSD_T(1);
+            // ---- 3. Gauss-Jordan over the sorted columns, a block of T at a time    OSD.py:31-72
+            // The sweep ends at the rank of H (:42-43) -- or as soon as no row without a pivot has a 1 left in
+            // the syndrome column: pivots found from there on would be chosen with a reduced syndrome bit of 0,
+            // which XORs nothing into the syndrome bits above them and puts a 0 at their own column, so the
+            // solution is already what the full sweep would leave.  (BP's residual syndromes are light: the
+            // sweep typically ends after a small part of the columns.)
+            int rank = 0, k0 = 0;
+            bool open_rows = true;
+            while (k0 < K && rank < P.rank) {
+                {
+                    unsigned mine = 0;
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) mine |= (pc[i] < 0 ? 1u : 0u) & (sb >> i);
+                    open_rows = __syncthreads_or((int)mine) != 0;
+                    if (!open_rows) break;
+                }
+                const int wk = k0 >> 6, sh = k0 & 63, nw = Wc - wk;
+                int T = 8;
+                while (T > 1 && ((k0 & (T - 1)) || ((size_t)nw << T) * 8 > (size_t)Wk.lds_table)) T >>= 1;
+                const int Tc = K - k0 < T ? K - k0 : T;
+                unsigned bt[RPT], D[RPT];
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = tid + i * nt;
+                    bt[i] = r < m ? (unsigned)(At[(size_t)wk * m + r] >> sh) & ((1u << Tc) - 1u) : 0u;
+                    D[i] = 0u;
+                }
+                int prow[8];
+                bool any = false;
+                OSD_T(2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    prow[j] = -1;
+                    if (j >= Tc || rank >= P.rank) continue;          // (uniform)
+                    // (this wavefront's first candidate through ballot + readlane, then one LDS atomic per
+                    // wavefront: a thousand lanes on one LDS word took 8 000 cycles per column)
+                    unsigned cand = ~0u;
+#pragma unroll
+                    for (int i = RPT - 1; i >= 0; --i) {
+                        const u64 b = __ballot(pc[i] < 0 && ((bt[i] >> j) & 1u));
+                        if (b) {
+                            const int l = __builtin_ctzll(b);
+                            const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)((D[i] << 8) | bt[i]), l);
+                            cand = ((unsigned)((tid & ~63) + l + i * nt) << 16) | v;
+                        }
+                    }
+                    unsigned* const slot = &s_piv[col_ctr % 3u];
+                    if ((tid & 63) == 0 && cand != ~0u) atomicMin(slot, cand);
+                    __syncthreads();
+                    const unsigned key = *slot;                       // first unused row with a 1 (:46-50)
+                    if (tid == 0) s_piv[(col_ctr + 2u) % 3u] = ~0u;   // (the slot of two columns ahead: idle now)
+                    ++col_ctr;
+                    if (key == ~0u) continue;                         // depends on earlier columns (:52-53)
+                    ++rank;
+                    any = true;
+                    const int p = (int)(key >> 16);
+                    const unsigned Bp = key & 0xffu, cs = (1u << j) | ((key >> 8) & 0xffu);
+                    prow[j] = p;
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + i * nt;
+                        if (r == p) pc[i] = idx[k0 + j];
+                        else if ((bt[i] >> j) & 1u) { bt[i] ^= Bp; D[i] ^= cs; }            // :63-68, on the bytes
+                    }
+                }
+                k0 += T;
+                OSD_T(3);
+                if (!any) continue;
+                unsigned* const nact = &s_nact[blk_ctr & 1u];
+                if (act) {
+                    // the rows this block changes, as (row, D) words in LDS: the update below is spread over all
+                    // threads (a block touches some 40 of the rows of a sparse matrix)
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const bool a = D[i] != 0u;
+                        const u64 b = __ballot(a);
+                        if (b) {
+                            unsigned base = 0;
+                            if ((tid & 63) == 0) base = atomicAdd(nact, (unsigned)__builtin_popcountll(b));
+                            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                            if (a) act[base + (unsigned)__builtin_popcountll(b & ((1ull << (tid & 63)) - 1ull))] =
+                                       ((unsigned)(tid + i * nt) << 8) | D[i];
+                        }
+                    }
+                    if (tid == 0) s_nact[(blk_ctr + 1u) & 1u] = 0u;       // (the next block's counter: idle now)
+                }
+                ++blk_ctr;
+                // the block's pivot rows as they were when the block began -> LDS
+                for (int it = tid; it < 8 * nw; it += nt) {
+                    const int j = it / nw, w = it - j * nw;
+                    int p = -1;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q == j) p = prow[q];
+                    Qs[it] = p >= 0 ? At[(size_t)(wk + w) * m + p] : 0ull;
+                }
+                __syncthreads();
+                OSD_T(4);
+                // every XOR combination of them
+                if (T == 8) {
+                    // an item: word w, the eight entries x = 8 xh .. 8 xh + 7 (Gray order over the low three rows)
+                    for (int it = tid; it < nw * 32; it += nt) {
+                        const int xh = it / nw, w = it - xh * nw;
+                        u64 v = 0ull;
+#pragma unroll
+                        for (int j = 3; j < 8; ++j) if ((xh >> (j - 3)) & 1) v ^= Qs[j * nw + w];
+                        const u64 q0 = Qs[w], q1 = Qs[nw + w], q2 = Qs[2 * nw + w];
+                        u64* const t = table + (size_t)(xh * 8) * nw + w;
+                        t[0] = v;                     v ^= q0;
+                        t[(size_t)1 * nw] = v;        v ^= q1;
+                        t[(size_t)3 * nw] = v;        v ^= q0;
+                        t[(size_t)2 * nw] = v;        v ^= q2;
+                        t[(size_t)6 * nw] = v;        v ^= q0;
+                        t[(size_t)7 * nw] = v;        v ^= q1;
+                        t[(size_t)5 * nw] = v;        v ^= q0;
+                        t[(size_t)4 * nw] = v;
+                    }
+                } else {
+                    for (int it = tid; it < (nw << T); it += nt) {
+                        const int x = it / nw, w = it - x * nw;
+                        u64 v = 0ull;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if ((x >> j) & 1) v ^= Qs[j * nw + w];
+                        table[it] = v;
+                    }
+                }
+                __syncthreads();
+                OSD_T(5);
+                if (act) {
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i)
+                        if (D[i]) sb ^= ((unsigned)table[(size_t)D[i] * nw + nw - 1] & 1u) << i;
+                    const int na = (int)*nact, items = na * nw;
+                    OSD_STAT(1, tid == 0 ? na : 0); OSD_STAT(2, tid == 0 ? items : 0);
+                    for (int it0 = tid; it0 < items; it0 += 4 * nt) {
+                        u64 v[4], t[4];
+                        u64* a[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int it = it0 + q * nt;
+                            if (it < items) {
+                                const int w = it / na;
+                                const unsigned e = act[it - w * na];
+                                a[q] = At + (size_t)(wk + w) * m + (e >> 8);
+                                t[q] = table[(size_t)(e & 0xffu) * nw + w];
+                                v[q] = *a[q];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (it0 + q * nt < items) *a[q] = v[q] ^ t[q];
+                    }
+                } else
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = tid + i * nt;
+                    if (D[i] == 0u) continue;                         // (r >= m: never set)
+                    OSD_STAT(1, 1); OSD_STAT(2, nw);
+                    const u64* const trow = table + (size_t)D[i] * nw;
+                    u64* const arow = At + (size_t)wk * m + r;
+                    sb ^= ((unsigned)trow[nw - 1] & 1u) << i;
+                    // (eight loads in flight, then eight stores: the compiler cannot tell that the planes do not
+                    // alias and would otherwise wait for every store before the next load)
+                    for (int w0 = 0; w0 < nw; w0 += 8) {
+                        u64 v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (w0 + q < nw) v[q] = arow[(size_t)(w0 + q) * m];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (w0 + q < nw) arow[(size_t)(w0 + q) * m] = v[q] ^ trow[w0 + q];
+                    }
+                }
+                // (the barrier at the top of the next block comes before anyone reads a row again or
+                // overwrites Qs / the table)
+                OSD_SYNC();
+                if (tid == 0) { OSD_STAT(0, 1); }
+                OSD_T(6);
+            }
+            OSD_STAT(7, tid == 0 ? 1 : 0);
+#ifdef QBP_OSD_TIMING
+            if (tid == 0) atomicMax(&g_osd_stat[3], (unsigned long long)k0);
+#endif
+            OSD_STAT(4, tid == 0 ? k0 : 0); OSD_STAT(5, tid == 0 ? rank : 0); OSD_STAT(6, tid == 0 && !open_rows ? 1 : 0);
+            if (rank >= P.rank || !open_rows || K >= n) break;
+            __syncthreads();                  // (next sweep: pos overwrites the table)
+        }
+        // ---- 4. e[pivot column] = reduced syndrome bit; solution = hard + e         OSD.py:14-26
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            // (sb: the thread's running copy of its rows' bits in the syndrome plane)
+            if (pc[i] >= 0 && ((sb >> i) & 1u)) sol[pc[i]] ^= 1u;                     // distinct pivot columns
+        }
+        if (tid == 0) { s_lm = 0ull; s_ew = 0; s_df = 0; s_bad = 0; }
+        __syncthreads();
+        if (P.solution)
+            for (int i = tid; i < n; i += nt) P.solution[rec * n + i] = sol[i];
+        if (P.errors) {
+            const uint8_t* err = P.errors + rec * n;
+            u64 lm = 0ull;
+            int ew = 0;
+            unsigned df = 0, bad = 0;
+            for (int i = tid; i < n; i += nt) {
+                const unsigned e = err[i] & 1u;
+                const unsigned res = sol[i] ^ e;
+                ew += (int)e;
+                df |= res;
+                if (res) lm ^= P.lx_cols[i];
+            }
+            for (int r = tid; r < m; r += nt) {
+                unsigned par = syn[r] & 1u;
+                for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) par ^= sol[P.col_idx[e]];
+                bad |= par;
+            }
+            if (lm) atomicXor(&s_lm, lm);
+            if (ew) atomicAdd(&s_ew, ew);
+            if (df) atomicOr(&s_df, 1);
+            if (bad) atomicOr(&s_bad, 1);
+            __syncthreads();
+            if (tid == 0) {
+                auto add = [&](int i) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + i), 1ull);
+                };
+                const bool logical = s_lm != 0ull;
+                if (!s_bad && !logical && s_df) add(5);
+                if (logical) {
+                    add(1);
+                    add(s_ew < P.half_distance ? 3 : 4);
+                    add(8);
+                }
+                if (!s_df) add(9);
+                if (s_bad) add(10);
+            }
+        }
+        __syncthreads();
+        OSD_T(7);
+    }
+    OSD_TEND();
 }
 
 #endif  // QBP_DEFINE_KERNELS

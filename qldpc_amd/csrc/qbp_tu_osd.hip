@@ -38,6 +38,50 @@ hipError_t launch_osd_big(unsigned grid, size_t lds, const OsdParams& O, const O
     return hipGetLastError();
 }
 
+template <int RPT>
+static hipError_t launch_osd_blocked_rpt(unsigned grid, size_t lds, const OsdParams& O, const OsdBigWorkspace& Wk,
+                                         hipStream_t s)
+{
+    static thread_local size_t lds_set[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || lds_set[dev] < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(osd0_blocked_kernel<RPT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) lds_set[dev] = lds;
+    }
+    hipLaunchKernelGGL(osd0_blocked_kernel<RPT>, dim3(grid), dim3(1024), lds, s, O, Wk);
+    return hipGetLastError();
+}
+
+// rows per thread: m <= 1024 * rows_per_thread (1, 2, 4 or 8)
+hipError_t launch_osd_blocked(int rows_per_thread, unsigned grid, size_t lds, const OsdParams& O,
+                              const OsdBigWorkspace& Wk, hipStream_t s)
+{
+    switch (rows_per_thread) {
+        case 1: return launch_osd_blocked_rpt<1>(grid, lds, O, Wk, s);
+        case 2: return launch_osd_blocked_rpt<2>(grid, lds, O, Wk, s);
+        case 4: return launch_osd_blocked_rpt<4>(grid, lds, O, Wk, s);
+        case 8: return launch_osd_blocked_rpt<8>(grid, lds, O, Wk, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+#ifdef QBP_OSD_TIMING
+extern "C" int qbp_debug_osd_timing(unsigned long long* out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_osd_timing), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_osd_stat), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_osd_timing), z, sizeof(z));
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_osd_stat), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
+
 hipError_t launch_hist_minmax(int grid, const double* x, long long count, double* part, hipStream_t s)
 {
     hipLaunchKernelGGL(hist_minmax_kernel, dim3(grid), dim3(256), 0, s, x, count, part);

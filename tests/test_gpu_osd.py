@@ -140,16 +140,18 @@ def _fresh_decoder(H):
 
 @pytest.mark.parametrize("tag", TAGS)
 def test_big_osd_kernel_equals_reference_goldens(tag):
-    """The workgroup-per-syndrome OSD-0 kernel (matrix copy in global memory: the path of matrices whose
+    """The workgroup-per-syndrome OSD-0 kernels (matrix copy in global memory: the path of matrices whose
     bit-packed rows exceed 64 KiB of LDS), forced onto the small codes: same solutions as the
-    reference's performOSD and as the one-wavefront kernel."""
+    reference's performOSD and as the one-wavefront kernel -- eight pivots at a time (1), one pivot at a
+    time (2), and eight at a time with a first sweep that runs out of columns (3)."""
     c = load_osd(tag)
     H = c["H"].astype(np.int64)
     dec = _fresh_decoder(H)
     small = dec.osd0(c["syndromes"], c["llr"], c["hard"])
-    dec.set_option(_lib.OPT_OSD_BIG, 1)
-    big = dec.osd0(c["syndromes"], c["llr"], c["hard"])
-    assert np.array_equal(big, c["solution"]) and np.array_equal(big, small)
+    for kind in (1, 2, 3):
+        dec.set_option(_lib.OPT_OSD_BIG, kind)
+        big = dec.osd0(c["syndromes"], c["llr"], c["hard"])
+        assert np.array_equal(big, c["solution"]) and np.array_equal(big, small), kind
 
 
 def test_osd_beyond_the_lds_limit():
@@ -172,13 +174,17 @@ def test_osd_beyond_the_lds_limit():
     err = (rng.random((40, n)) < p).astype(np.uint8)
     syn = (err @ H.T % 2).astype(np.uint8)
     hard, conv, iters, llr = dec.decode(syn, mc.prior_of(p, n), 12)
-    f = np.flatnonzero(~conv)[:8]
+    f = np.flatnonzero(~conv)[:24]
     assert len(f) >= 3
     got = dec.osd0(syn[f], llr[f], hard[f])
     assert np.array_equal((got.astype(np.int64) @ H.T) % 2, syn[f])
     assert np.array_equal(got[0], oracle.osd0(H, syn[f[0]], llr[f[0]], hard[f[0]]))
     one = osd.performOSD(csr_matrix(H), syn[f[1]], llr[f[1]], hard[f[1]])
     assert np.array_equal(one, got[1])
+    # the one-pivot-at-a-time kernel and the two-sweep path of the blocked one: same solutions, all of them
+    for kind in (2, 3):
+        dec.set_option(_lib.OPT_OSD_BIG, kind)
+        assert np.array_equal(dec.osd0(syn[f], llr[f], hard[f]), got), kind
 
 
 def test_mc_osd_on_an_irregular_matrix_equals_oracle():
@@ -190,7 +196,7 @@ def test_mc_osd_on_an_irregular_matrix_equals_oracle():
     p = 0.05
     prior = mc.prior_of(p, code.n)
     want = oracle.mc_counters(H, code.Lx, code.distance, p, prior, 0, 4000, seed=2, max_iter=20, osd=True)
-    for big in (0, 1):
+    for big in (0, 1, 2, 3):
         dec = _fresh_decoder(H)
         assert dec.info("kernel_kind") == 2
         dec.set_option(_lib.OPT_OSD_BIG, big)

@@ -33,13 +33,26 @@ for name, H in (("1728x5184", block_diag([csr_matrix(st144), csr_matrix(st144)])
     syn = np.asarray((csr_matrix(err.astype(np.int64)) @ H.T.astype(np.int64)).todense() % 2).astype(np.uint8)
     hard, conv, iters, llr = dec.decode(syn, mc.prior_of(p, n), 12)
     f = np.flatnonzero(~conv)[:256]
+    kind = int(os.environ.get("QBP_OSD_KIND", "0"))
+    if kind:
+        dec.set_option(_lib.OPT_OSD_BIG, kind)
+    rep = int(os.environ.get("QBP_OSD_REP", "1"))
+    f = np.tile(f, rep)
     dec.osd0(syn[f[:2]], llr[f[:2]], hard[f[:2]])          # tables, rank (host, once)
+    import torch
+    ds, dl, dh = (torch.from_numpy(np.ascontiguousarray(x[f])).cuda() for x in (syn, llr, hard))
+    dsol = torch.empty((len(f), n), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream()
+    dec.osd0_device(ds.data_ptr(), dl.data_ptr(), dh.data_ptr(), len(f), dsol.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    got = dec.osd0(syn[f], llr[f], hard[f])
+    dec.osd0_device(ds.data_ptr(), dl.data_ptr(), dh.data_ptr(), len(f), dsol.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    got = dsol.cpu().numpy()
     ok = bool((np.asarray(csr_matrix(got.astype(np.int64)) @ H.T.astype(np.int64).todense() if False else
                           (csr_matrix(got.astype(np.int64)) @ H.T.astype(np.int64)).todense()) % 2 == syn[f]).all())
-    out[name] = {"failures": int(len(f)), "seconds": round(dt, 4), "osd_per_s": round(len(f) / dt, 1), "all_valid": ok,
+    out[name] = {"failures": int(len(f)), "seconds": round(dt, 4), "osd_per_s": round(len(f) / dt, 1), "all_valid": ok, "kind": kind,
                  "checksum": int(got.astype(np.int64).sum())}
     dec.close()
 print(json.dumps(out))
