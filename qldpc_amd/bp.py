@@ -157,8 +157,14 @@ def _decoder_for(H, device):
                _digest(np.ascontiguousarray(S.indices)), _digest(np.ascontiguousarray(S.data)),
                device)
     else:
-        A = np.ascontiguousarray(H)
-        key = ("d", A.shape, A.dtype.str, _digest(A), device)
+        A = np.asarray(H)
+        if A.ndim == 2 and A.flags.f_contiguous and not A.flags.c_contiguous:
+            # (the reference's codes/*.npz matrices are Fortran-ordered: hash the buffer as it lies, no copy;
+            # the layout is part of the key -- numpy's summation order, hence the decode flags, depend on it)
+            key = ("f", A.shape, A.dtype.str, _digest(A.T), device)
+        else:
+            A = np.ascontiguousarray(A)
+            key = ("d", A.shape, A.dtype.str, _digest(A), device)
     dec = _DECODERS.get(key)
     if dec is None:
         row_ptr, col_idx, m, n = csr_from_H(H)

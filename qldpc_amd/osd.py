@@ -60,7 +60,10 @@ def _from_last_batch(dec, syn, l, hd):
 
 
 def performOSD(H, syndrome, llr, hard):
-    dec = decoder_for(H)
+    return _osd0(decoder_for(H), syndrome, llr, hard)
+
+
+def _osd0(dec, syndrome, llr, hard):
     syn = (np.asarray(syndrome).astype(np.int64) % 2).astype(np.uint8)
     hd = (np.asarray(hard).astype(np.int64) % 2).astype(np.uint8)
     l = np.asarray(llr, dtype=np.float64)
@@ -78,12 +81,17 @@ def performOSD_batch(H, syndromes, llrs, hards):
 
 
 def performOSD_enhanced(H, syndrome, llr, hard, order=0, max_combinations=None):
-    sol = performOSD(H, syndrome, llr, hard)
+    dec = decoder_for(H)
+    sol = _osd0(dec, syndrome, llr, hard)
     if order == 0:
         return sol
-    from scipy.sparse import issparse
-    Hd = H.toarray() if issparse(H) else np.asarray(H)
-    if np.array_equal((sol @ (Hd != 0).astype(np.int64).T) % 2, np.asarray(syndrome).astype(np.int64) % 2):
+    # (sol @ H.T) % 2 == syndrome, through the decoder's CSR: XOR of the solution bits of every row's columns
+    rp, ci = dec.row_ptr, dec.col_idx
+    par = np.zeros(dec.m, np.int64)
+    full = np.flatnonzero(rp[1:] > rp[:-1])          # (reduceat has no identity for an empty row)
+    if len(full):
+        par[full] = np.bitwise_xor.reduceat(sol[ci], rp[:-1][full]) & 1
+    if np.array_equal(par, np.asarray(syndrome).astype(np.int64) % 2):
         return sol                                   # the reference returns here as well
     raise NotImplementedError("performOSD_enhanced(order > 0) on a syndrome outside the column space "
                               "of H: the reference's combinatorial search is not implemented")
