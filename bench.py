@@ -638,6 +638,14 @@ def other_config_legs(device, num_cu):
                     "pmc_file": os.path.relpath(PMC_LEGS, ROOT), "kernels": [d["kernel"] for d in disp],
                     "SQ_INSTS_VALU": valu,
                     "pmc_kernel_ms": [next(iter(d["duration_ns"].values())) / 1e6 if d["duration_ns"] else None for d in disp]}
+            if all("FETCH_SIZE" in d["counters"] and "WRITE_SIZE" in d["counters"] for d in disp):
+                # KiB -> bytes; reads x 2 (gfx950: FETCH_SIZE counts 64 B per 128-B request), as for the headline
+                rd = sum(d["counters"]["FETCH_SIZE"] for d in disp) * 1024.0
+                wr = sum(d["counters"]["WRITE_SIZE"] for d in disp) * 1024.0
+                roof["traffic"] = 2.0 * rd + wr
+                roof["traffic_detail"] = {"read_bytes_raw": rd, "read_bytes_x2_gfx950": 2.0 * rd, "write_bytes": wr,
+                                          "unit": "bytes per launch (PMC passes of their own, same launches)",
+                                          "HBM_GBps_at_this_rate": (2.0 * rd + wr) / (r["kernel_ms"] * 1e-3) / 1e9}
             if main.get("SQ_WAVE_CYCLES"):
                 w = main["SQ_WAVE_CYCLES"]
                 roof["wave_cycle_shares_last_kernel"] = {

@@ -142,7 +142,7 @@ def test_fuzz_decode_kernels_vs_oracle():
 
 def test_fuzz_osd_vs_oracle():
     rng = np.random.default_rng(77)
-    done = 0
+    done = big = 0
     for case in range(max(CASES // 4, 8)):
         kind, H = random_matrix(rng)
         m, n = H.shape
@@ -153,16 +153,32 @@ def test_fuzz_osd_vs_oracle():
             llr = np.round(llr)                                   # many ties in |llr|
         hard = (llr < 0).astype(np.uint8)
         err = (rng.random((B, n)) < 0.1).astype(np.int64)
-        syn = (err @ H.T % 2).astype(np.uint8)                    # always in the column space
+        syn = (err @ H.T % 2).astype(np.uint8)                    # in the column space ...
+        consistent = rng.random() < 0.8
+        if not consistent:                                        # ... or anywhere (the sweep then runs to the rank)
+            syn = (rng.random((B, m)) < 0.5).astype(np.uint8)
+        elif rng.random() < 0.3:                                  # light residuals, as BP leaves them: early end
+            hard = ((err + (rng.random((B, n)) < 0.02)) % 2).astype(np.uint8)
         sol = dec.osd0(syn, llr, hard)
         for i in range(B):
             ref = oracle.osd0(H, syn[i], llr[i], hard[i])
             assert np.array_equal(sol[i], ref), f"OSD-0 differs: case {case} {kind} {m}x{n}"
-            assert np.array_equal(sol[i].astype(np.int64) @ H.T % 2, syn[i])
+            if consistent:
+                assert np.array_equal(sol[i].astype(np.int64) @ H.T % 2, syn[i])
+        if case % 3 == 0:
+            # the kernels for matrices beyond the LDS limit, forced: eight pivots per pass (1), one pivot at a
+            # time (2), eight per pass with several sweeps (3) -- a decoder of its own (options must not leak)
+            own = _lib.Decoder(*bp.csr_from_H(H), bp.DEVICE)
+            for k in (1, 2, 3):
+                own.set_option(_lib.OPT_OSD_BIG, k)
+                assert np.array_equal(own.osd0(syn, llr, hard), sol), f"OSD kernel {k}: case {case} {kind} {m}x{n}"
+            own.close()
+            big += B
         done += B
         if (case + 1) % 500 == 0:
             print(f"  ... {case + 1} OSD cases", flush=True)
-    print(f"fuzz OSD-0: {done} solutions identical to the oracle")
+    print(f"fuzz OSD-0: {done} solutions identical to the oracle; {big} of them through the three "
+          f"workgroup-per-syndrome kernels as well")
 
 
 def test_fuzz_mc_counters_vs_oracle():

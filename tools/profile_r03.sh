@@ -35,6 +35,8 @@ fi
 L="python3 $R/tools/bench_legs.py --once"
 pass legs_total "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" $L
 pass legs_wait "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" $L
+pass legs_fetch "FETCH_SIZE" $L
+pass legs_write "WRITE_SIZE" $L
 cd $R
 python3 tools/pmc_collect.py $OUT > $OUT/summary_pmc.json
 python3 tools/pmc_collect.py $OUT legs > $OUT/summary_legs.json
