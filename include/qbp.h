@@ -219,7 +219,9 @@ int qbp_mc_run_errors(qbp_handle* h, const uint8_t* Lx, int32_t k, int32_t dista
  * OSD-0 post-processing of B decoder outputs: decoding/OSD.py:3-28 performOSD (= OSD_enhanced.py
  * with order 0), any matrix size.  syndromes [B][m], llr [B][n], hard [B][n] -> solution [B][n].  Columns are
  * ordered by ascending |llr|; equal values by ascending column index (np.argsort's order of
- * equal keys is unspecified in the reference).
+ * equal keys is unspecified in the reference).  A syndrome outside the column space of H gets the reference's
+ * output too: there it depends on the row swaps of gf2_elimination (OSD.py:56-59); the records whose sweep
+ * shows that are recomputed by a kernel that follows the swaps, in a second launch on the same stream.
  */
 int qbp_osd0_batch(qbp_handle* h, const uint8_t* syndromes, const double* llr, const uint8_t* hard,
                    int64_t B, uint8_t* solution);

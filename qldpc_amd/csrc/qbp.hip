@@ -156,7 +156,9 @@ struct qbp_handle {
     bool osd_big_ready = false;     // tables of the workgroup-per-syndrome kernel built (lazily)
     int osd_W = 0, osd_NP = 0, osd_lds = 0, osd_rank = 0;
     DevBuf<uint32_t> d_osd_At;
-    DevBuf<int32_t> d_osd_piv, d_osd_idx;
+    DevBuf<int32_t> d_osd_piv, d_osd_idx, d_osd_posn;
+    DevBuf<unsigned long long> d_osd_next;   // work counter of osd0_blocked_kernel
+    DevBuf<long long> d_osd_redo;   // [0]: count, [1..]: records whose OSD sweep found the syndrome inconsistent
     DevBuf<uint8_t> d_osd_sol;
     DevBuf<unsigned long long> d_osd_keys;
     DevBuf<uint32_t> d_hbits;
@@ -896,6 +898,7 @@ void qbp_destroy(qbp_handle* h)
     h->f_order.tab_nbr.release(); h->f_order.tab_writer.release(); h->f_order.col_edge.release();
     h->f_order.sedge.release(); h->f_order.vpos.release(); h->f_order.vrow.release();
     h->d_osd_At.release(); h->d_osd_piv.release(); h->d_osd_idx.release(); h->d_osd_sol.release();
+    h->d_osd_posn.release(); h->d_osd_redo.release(); h->d_osd_next.release();
     h->d_osd_keys.release();
     h->d_fail_list.release(); h->d_fail_count.release(); h->d_fail_syn.release();
     h->d_fail_hard.release(); h->d_fail_err.release(); h->d_fail_llr.release();
@@ -1312,69 +1315,89 @@ static int osd_big_prepare(qbp_handle* h)
     return QBP_OK;
 }
 
-static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hipStream_t s)
+// The one-pivot-at-a-time kernel, which follows the reference's row swaps (qbp_osd.hpp, osd0_big_kernel): matrices
+// beyond 8192 rows, QBP_OPT_OSD_BIG = 2, and the records a fast kernel found inconsistent.
+static int osd_launch_swaps(qbp_handle* h, const qbp::OsdParams& O, long long max_grid, hipStream_t s)
+{
+    const size_t m = h->m, n = h->n, RS = (size_t)h->osd_W + 1, NP = (size_t)h->osd_NP;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(max_grid, (long long)h->num_cu * 2));
+    qbp::OsdBigWorkspace Wk{};
+    Wk.keys_in_lds = NP * 12 <= (size_t)96 * 1024 ? 1 : 0;
+    HIP_TRY(h->d_osd_At.reserve((size_t)grid * RS * m));
+    HIP_TRY(h->d_osd_piv.reserve((size_t)grid * m));
+    HIP_TRY(h->d_osd_posn.reserve((size_t)grid * 2 * m));
+    HIP_TRY(h->d_osd_sol.reserve((size_t)grid * n));
+    if (!Wk.keys_in_lds) {
+        HIP_TRY(h->d_osd_keys.reserve((size_t)grid * NP));
+        HIP_TRY(h->d_osd_idx.reserve((size_t)grid * NP));
+    }
+    Wk.At = h->d_osd_At.p; Wk.pivcol = h->d_osd_piv.p; Wk.posn = h->d_osd_posn.p; Wk.sol = h->d_osd_sol.p;
+    Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
+    HIP_TRY(qbp::launch_osd_big((unsigned)grid, Wk.keys_in_lds ? NP * 12 : 0, O, Wk, s));
+    return QBP_OK;
+}
+
+// `redo`: the caller's syndromes may lie outside the column space of H (anything but the Monte-Carlo loop, whose
+// syndromes come from errors): the fast kernels then list the records whose sweep says so, and the kernel that
+// follows the reference's row swaps recomputes them (an empty list costs one small launch).
+static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hipStream_t s, bool redo = false)
 {
     O.m = h->m; O.n = h->n; O.W = h->osd_W; O.NP = h->osd_NP;
     O.row_ptr = h->d_row_ptr.p; O.col_idx = h->d_col_idx.p;
     if (!h->osd_ok) {
-        // matrices whose rows do not fit 64 KiB of LDS: one workgroup per syndrome, working copy of
-        // [H | s] in a global workspace (qbp_osd.hpp: osd0_blocked_kernel; osd0_big_kernel beyond 8192 rows)
+        // matrices whose rows do not fit 64 KiB of LDS (rank and 32-bit rows: built on first use)
         int rc = osd_big_prepare(h);
         if (rc) return rc;
-        O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
-        const size_t m = h->m, n = h->n, RS = (size_t)h->osd_W + 1, NP = (size_t)h->osd_NP;
-        qbp::OsdBigWorkspace Wk{};
-        // -- eight pivots at a time
-        const size_t wc_max = (n + 63) / 64 + 1;
-        const size_t LDS_MAX = 160 * 1024 - 64;                      // (static __shared__ of the kernel: 40 bytes)
-        const size_t qs = 8 * wc_max * 8;
-        const size_t want_table = std::min<size_t>(96 * 1024, 256 * wc_max * 8);
-        size_t region0 = std::max(want_table, NP * 8), lds = region0 + qs + NP * 4 + ((n + 15) & ~(size_t)15);
-        Wk.keys_in_lds = 1;
-        if (lds > LDS_MAX) { Wk.keys_in_lds = 0; region0 = want_table; lds = region0 + qs; }
-        const bool blocked = h->opt_osd_big != 2 && m <= 8192 && lds <= LDS_MAX && 2 * wc_max * 8 <= want_table;
-        if (blocked) {
-            const int grid = (int)std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu));
-            Wk.wc_max = (int)wc_max;
-            // first sweep: the 2048 least reliable columns (a sweep ends where no unpivoted row has a syndrome
-            // bit left -- after some 200 columns on the BP failures of the space-time matrices in the tests,
-            // 1632 at most)
-            Wk.k_first = h->opt_osd_big == 3 ? 24 : (int)std::min<size_t>(n, 2048);
-            if (lds + m * 4 <= LDS_MAX && h->opt_osd_big != 3) { Wk.lds_act = (int)lds; lds += m * 4; }
-            HIP_TRY(h->d_osd_piv.reserve(2));
-            HIP_TRY(hipMemsetAsync(h->d_osd_piv.p, 0, 8, s));
-            Wk.next = reinterpret_cast<unsigned long long*>(h->d_osd_piv.p);
-            Wk.lds_region0 = (int)region0; Wk.lds_table = (int)want_table;
-            HIP_TRY(h->d_osd_At.reserve((size_t)grid * wc_max * m * 2));
-            if (!Wk.keys_in_lds) {
-                HIP_TRY(h->d_osd_sol.reserve((size_t)grid * n));
-                HIP_TRY(h->d_osd_keys.reserve((size_t)grid * NP));
-                HIP_TRY(h->d_osd_idx.reserve((size_t)grid * NP));
-            }
-            Wk.At = h->d_osd_At.p; Wk.sol = h->d_osd_sol.p; Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
-            const int rpt = m <= 1024 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 4 : 8;
-            HIP_TRY(qbp::launch_osd_blocked(rpt, (unsigned)grid, lds, O, Wk, s));
-            return QBP_OK;
-        }
-        // -- one pivot at a time
-        const int grid = (int)std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 2));
-        Wk.keys_in_lds = NP * 12 <= (size_t)96 * 1024 ? 1 : 0;
-        HIP_TRY(h->d_osd_At.reserve((size_t)grid * RS * m));
-        HIP_TRY(h->d_osd_piv.reserve((size_t)grid * m));
-        HIP_TRY(h->d_osd_sol.reserve((size_t)grid * n));
+    }
+    O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
+    const size_t m = h->m, n = h->n, NP = (size_t)h->osd_NP;
+    // -- matrices beyond the LDS limit: eight pivots at a time (qbp_osd.hpp, osd0_blocked_kernel)
+    qbp::OsdBigWorkspace Wk{};
+    const size_t wc_max = (n + 63) / 64 + 1;
+    const size_t LDS_MAX = 160 * 1024 - 64;                          // (static __shared__ of the kernel: 64 bytes)
+    const size_t qs = 8 * wc_max * 8;
+    const size_t want_table = std::min<size_t>(96 * 1024, 256 * wc_max * 8);
+    size_t region0 = std::max(want_table, NP * 8), lds = region0 + qs + NP * 4 + ((n + 15) & ~(size_t)15);
+    Wk.keys_in_lds = 1;
+    if (lds > LDS_MAX) { Wk.keys_in_lds = 0; region0 = want_table; lds = region0 + qs; }
+    const bool blocked = !h->osd_ok && h->opt_osd_big != 2 && m <= 8192 && lds <= LDS_MAX && 2 * wc_max * 8 <= want_table;
+    if (!h->osd_ok && !blocked) return osd_launch_swaps(h, O, max_items, s);
+    if (redo) {
+        HIP_TRY(h->d_osd_redo.reserve((size_t)max_items + 1));
+        HIP_TRY(hipMemsetAsync(h->d_osd_redo.p, 0, 8, s));
+        O.redo = h->d_osd_redo.p;
+    }
+    if (blocked) {
+        const int grid = (int)std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu));
+        Wk.wc_max = (int)wc_max;
+        // first sweep: the 2048 least reliable columns (a sweep ends where no unpivoted row has a syndrome
+        // bit left -- after some 200 columns on the BP failures of the space-time matrices in the tests,
+        // 1632 at most)
+        Wk.k_first = h->opt_osd_big == 3 ? 24 : (int)std::min<size_t>(n, 2048);
+        if (lds + m * 4 <= LDS_MAX && h->opt_osd_big != 3) { Wk.lds_act = (int)lds; lds += m * 4; }
+        HIP_TRY(h->d_osd_next.reserve(1));
+        HIP_TRY(hipMemsetAsync(h->d_osd_next.p, 0, 8, s));
+        Wk.next = h->d_osd_next.p;
+        Wk.lds_region0 = (int)region0; Wk.lds_table = (int)want_table;
+        HIP_TRY(h->d_osd_At.reserve((size_t)grid * wc_max * m * 2));
         if (!Wk.keys_in_lds) {
+            HIP_TRY(h->d_osd_sol.reserve((size_t)grid * n));
             HIP_TRY(h->d_osd_keys.reserve((size_t)grid * NP));
             HIP_TRY(h->d_osd_idx.reserve((size_t)grid * NP));
         }
-        Wk.At = h->d_osd_At.p; Wk.pivcol = h->d_osd_piv.p; Wk.sol = h->d_osd_sol.p;
-        Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
-        const size_t lds1 = Wk.keys_in_lds ? NP * 12 : 0;
-        HIP_TRY(qbp::launch_osd_big((unsigned)grid, lds1, O, Wk, s));
-        return QBP_OK;
+        Wk.At = h->d_osd_At.p; Wk.sol = h->d_osd_sol.p; Wk.keys = h->d_osd_keys.p; Wk.idx = h->d_osd_idx.p;
+        const int rpt = m <= 1024 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 4 : 8;
+        HIP_TRY(qbp::launch_osd_blocked(rpt, (unsigned)grid, lds, O, Wk, s));
+    } else {
+        const long long grid = std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 32));
+        HIP_TRY(qbp::launch_osd_small(h->osd_W + 1, (unsigned)grid, (size_t)h->osd_lds, O, s));
     }
-    O.rank = h->osd_rank; O.hbits = h->d_hbits.p;
-    const long long grid = std::max<long long>(1, std::min<long long>(max_items, (long long)h->num_cu * 32));
-    HIP_TRY(qbp::launch_osd_small(h->osd_W + 1, (unsigned)grid, (size_t)h->osd_lds, O, s));
+    if (redo) {
+        qbp::OsdParams R = O;
+        R.redo = nullptr; R.count = 0;
+        R.count_ptr = h->d_osd_redo.p; R.list = h->d_osd_redo.p + 1;
+        return osd_launch_swaps(h, R, std::min<long long>(max_items, 32), s);
+    }
     return QBP_OK;
 }
 
@@ -1389,7 +1412,7 @@ try {
     HIP_TRY(on_device.err);
     qbp::OsdParams O{};
     O.count = B; O.syndromes = d_syndromes; O.llr = d_llr; O.hard = d_hard; O.solution = d_solution;
-    return osd_launch(h, O, B, static_cast<hipStream_t>(stream));
+    return osd_launch(h, O, B, static_cast<hipStream_t>(stream), true);
 }
 QBP_ABI_CATCH
 

@@ -1,9 +1,10 @@
 // OSD-0 post-processing on the GPU: decoding/OSD.py:3-72 (performOSD + gf2_elimination).
 //
 // One wavefront per syndrome.  The reference permutes the columns of H by ascending |LLR|, runs a
-// Gauss-Jordan elimination with row swaps and reads the solution off the pivot columns.  The
-// solution only depends on WHICH columns become pivots (the greedy, first-independent-columns
-// basis in reliability order) -- not on which row serves as the pivot -- so this kernel never
+// Gauss-Jordan elimination with row swaps and reads the solution off the pivot columns.  For a syndrome in
+// the column space of H (every syndrome that comes from an error) the solution only depends on WHICH columns
+// become pivots (the greedy, first-independent-columns basis in reliability order) -- not on which row
+// serves as the pivot (for the others see osd_flag_inconsistent below) -- so this kernel never
 // swaps or permutes: it keeps the bit-packed rows of H in LDS in their original column indexing,
 // walks the columns in sorted order, picks any not-yet-used row with a 1 in that column as the
 // pivot and XORs it into every other row that has the bit (rows are n bits + the syndrome bit).
@@ -33,6 +34,8 @@ struct OsdParams {
     const double* llr;              // [*][n]
     const uint8_t* hard;            // [*][n]
     uint8_t* solution;              // [*][n] (may be null in Monte-Carlo mode)
+    long long* redo;                // optional: [0] counts, [1..] lists the records whose sweep ended with a
+                                    // syndrome bit left on a row without a pivot (see osd_flag_inconsistent)
     // Monte-Carlo classification (paperResults_GPU.py:127-144 on the OSD output)
     const uint8_t* errors;          // [*][n] or null
     const unsigned long long* lx_cols;
@@ -67,6 +70,19 @@ __host__ __device__ inline size_t osd_region0_bytes(int m, int W, int NP)
 __host__ __device__ inline size_t osd_lds_bytes(int m, int n, int W, int NP)
 {
     return osd_region0_bytes(m, W, NP) + (size_t)NP * 2 + (size_t)m * 4 + (size_t)n + 16;
+}
+
+// A syndrome outside the column space of H (no error produces one; no caller of the reference passes one) ends its
+// sweep with a 1 left in the syndrome column of a row without a pivot.  There, and only there, the reference's
+// output depends on WHICH row served as the pivot of a column -- on its row swaps (OSD.py:56-59).  The fast kernels
+// pick the first unused row in the original order; they list such a record in P.redo, and the host launches
+// osd0_big_kernel, which follows the swaps, on the list (normally empty: the launch reads one counter and ends).
+__device__ __forceinline__ void osd_flag_inconsistent(const OsdParams& P, long long rec)
+{
+    if (P.redo) {
+        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(P.redo), 1ull);
+        P.redo[1 + at] = rec;
+    }
 }
 
 template <int WW>
@@ -177,6 +193,7 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
             if (lane == 0) pivcol[p] = c;
             __syncthreads();
         }
+        if (__ballot((sb & ~used) != 0u) && lane == 0) osd_flag_inconsistent(P, rec);
         // ---- 4. e[pivot column] = reduced syndrome bit; solution = hard + e    OSD.py:14-26
         for (int r = lane; r < m; r += 64) {
             const int c = pivcol[r];
@@ -237,10 +254,13 @@ __global__ __launch_bounds__(64) void osd0_kernel(const OsdParams P)
 // (word w of row r at At[w * m + r]) so that the threads of a wavefront -- one matrix row each -- read
 // and write consecutive addresses; sort keys in LDS when n <= 8192, else in the workspace too.
 // Same algorithm and tie rules as osd0_kernel above, hence the same solutions (tested on the small
-// codes, where both kernels apply).
+// codes, where both kernels apply) -- one pivot at a time, full-width rows, and the one kernel that follows the
+// reference's row swaps: it serves matrices beyond 8192 rows and the records the fast kernels list in P.redo.
 struct OsdBigWorkspace {
     uint32_t* At;                   // [grid][(W + 1) * m]
     int32_t* pivcol;                // [grid][m]
+    int32_t* posn;                  // [grid][2 m]: position of every row in the reference's swapped arrangement,
+                                    // then the row at every position (osd0_big_kernel)
     uint8_t* sol;                   // [grid][n]
     unsigned long long* keys;       // [grid][NP]   (only when the keys do not fit LDS)
     int32_t* idx;                   // [grid][NP]
@@ -258,7 +278,7 @@ struct OsdBigWorkspace {
 __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const OsdBigWorkspace Wk)
 {
     extern __shared__ double osd_smem[];
-    __shared__ int s_piv[2];        // (two slots, by column parity: see the pivot search)
+    __shared__ unsigned long long s_piv[2];   // (two slots, by column parity: see the pivot search)
     __shared__ unsigned long long s_lm;
     __shared__ int s_ew, s_df, s_bad;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -274,6 +294,8 @@ __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const 
     }
     uint32_t* const At = Wk.At + (size_t)blockIdx.x * RS * m;
     int* const pivcol = Wk.pivcol + (size_t)blockIdx.x * m;
+    int* const posn = Wk.posn + (size_t)blockIdx.x * 2 * m;        // position of row r in the swapped arrangement
+    int* const rowat = posn + m;                                   // row at position q
     uint8_t* const sol = Wk.sol + (size_t)blockIdx.x * n;
 
     const long long total = P.count_ptr ? *P.count_ptr : P.count;
@@ -311,9 +333,13 @@ __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const 
             for (int e = P.row_ptr[r]; e < P.row_ptr[r + 1]; ++e) par ^= sol[P.col_idx[e]];
             At[(size_t)W * m + r] = par;
             pivcol[r] = -1;
+            posn[r] = r;
+            rowat[r] = r;
         }
         __syncthreads();
         // ---- 3. Gauss-Jordan over the columns in reliability order                  OSD.py:31-72
+        // The pivot of a column is the first row at or below position `rank` of the reference's arrangement,
+        // which swaps every pivot row up (:46-59): rows keep their place here and carry that position along.
         int rank = 0;
         for (int k = 0; k < n && rank < P.rank; ++k) {
             const int c = idx[k];
@@ -321,16 +347,26 @@ __global__ __launch_bounds__(256) void osd0_big_kernel(const OsdParams P, const 
             const uint32_t bit = 1u << (c & 31);
             // (slot k & 1: a column without pivot leaves this iteration without a trailing barrier, so the
             // next column's reset must not touch the word the slower threads are still reading)
-            int* const piv = &s_piv[k & 1];
-            if (tid == 0) *piv = 0x7fffffff;
+            unsigned long long* const piv = &s_piv[k & 1];
+            if (tid == 0) *piv = ~0ull;
             __syncthreads();
-            int mine = 0x7fffffff;
+            unsigned long long mine = ~0ull;          // (position, row)
             for (int r = tid; r < m; r += nt)
-                if ((colw[r] & bit) && pivcol[r] < 0) { mine = r; break; }     // this thread's first
-            if (mine != 0x7fffffff) atomicMin(piv, mine);
+                if ((colw[r] & bit) && pivcol[r] < 0) {
+                    const unsigned long long key = ((unsigned long long)(unsigned)posn[r] << 32) | (unsigned)r;
+                    mine = key < mine ? key : mine;
+                }
+            if (mine != ~0ull) atomicMin(piv, mine);
             __syncthreads();
-            const int p = *piv;                       // the first unused row with a 1 (:46-50)
-            if (p == 0x7fffffff) continue;            // column depends on earlier ones (:52-53)
+            const unsigned long long key = *piv;      // the first unused row with a 1 (:46-50)
+            if (key == ~0ull) continue;               // column depends on earlier ones (:52-53)
+            const int q = (int)(key >> 32), p = (int)(unsigned)key;
+            if (tid == 0 && q != rank) {              // :56-59 (only this thread reads rowat; the trailing barrier
+                                                      // publishes posn)
+                const int r0 = rowat[rank];
+                rowat[rank] = p; rowat[q] = r0;
+                posn[p] = rank; posn[r0] = q;
+            }
             ++rank;
             for (int r = tid; r < m; r += nt) {
                 if (r != p && (colw[r] & bit)) {
@@ -712,8 +748,17 @@ __global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, c
 #ifdef QBP_OSD_TIMING
             if (tid == 0) atomicMax(&g_osd_stat[3], (unsigned long long)k0);
 #endif
+            if (open_rows) {                  // (the loop ended on one of its other conditions: look once more)
+                unsigned mine = 0;
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) mine |= (pc[i] < 0 ? 1u : 0u) & (sb >> i);
+                open_rows = __syncthreads_or((int)mine) != 0;
+            }
             OSD_STAT(4, tid == 0 ? k0 : 0); OSD_STAT(5, tid == 0 ? rank : 0); OSD_STAT(6, tid == 0 && !open_rows ? 1 : 0);
-            if (rank >= P.rank || !open_rows || K >= n) break;
+            if (rank >= P.rank || !open_rows || K >= n) {
+                if (open_rows && tid == 0) osd_flag_inconsistent(P, rec);
+                break;
+            }
             __syncthreads();                  // (next sweep: pos overwrites the table)
         }
         // ---- 4. e[pivot column] = reduced syndrome bit; solution = hard + e         OSD.py:14-26

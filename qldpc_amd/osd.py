@@ -4,6 +4,10 @@ Same positional signature and return type (int64 vector, ``(hard + e_correction)
 OSD.py:26-28).  Equal ``|llr|`` values are ordered by column index (the reference's ``np.argsort``
 leaves that order to the numpy build).
 
+A syndrome outside the column space of H (none of the reference's callers passes one) gets the reference's
+output as well: there it depends on the row swaps of the elimination, which a second kernel follows
+(qbp_osd.hpp, osd_flag_inconsistent; tests/golden/osd_inconsistent.npz).
+
 ``performOSD_enhanced`` (decoding/OSD_enhanced.py:5 = rework/decoding.py:193) returns its OSD-0
 solution whenever that solution reproduces the syndrome (OSD_enhanced.py "if np.all(osd0_syndrome
 == syndrome): return osd0_solution", before any higher-order search) -- which is the case for every

@@ -1,5 +1,7 @@
 """GPU: OSD-0 (qbp_osd0_batch) against the reference's performOSD outputs and the oracle; the
 BP+OSD Monte-Carlo path against the oracle pipeline and the reference's stored LER curves."""
+import os
+
 import numpy as np
 import pytest
 
@@ -152,6 +154,31 @@ def test_big_osd_kernel_equals_reference_goldens(tag):
         dec.set_option(_lib.OPT_OSD_BIG, kind)
         big = dec.osd0(c["syndromes"], c["llr"], c["hard"])
         assert np.array_equal(big, c["solution"]) and np.array_equal(big, small), kind
+
+
+@pytest.mark.parametrize("tag", ("72", "144", "288"))
+def test_osd_on_syndromes_outside_the_column_space_equals_reference(tag):
+    """tests/golden/osd_inconsistent.npz (the reference's performOSD on random syndromes, none in the column
+    space of H: its output there depends on the row swaps of its elimination, OSD.py:56-59).  The fast kernels
+    notice such a syndrome at the end of their sweep and hand the record to the kernel that follows the swaps:
+    same output as the reference through the drop-in function, the batch entry and every kernel selection."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "osd_inconsistent.npz"))
+    H = d[f"{tag}/H"].astype(np.int64)
+    syn, llr, hard, want = (d[f"{tag}/{k}"] for k in ("syndromes", "llr", "hard", "solution"))
+    assert np.array_equal(osd.performOSD(H, syn[0], llr[0], hard[0]), want[0])
+    dec = _fresh_decoder(H)
+    for kind in (0, 1, 2, 3):
+        dec.set_option(_lib.OPT_OSD_BIG, kind)
+        assert np.array_equal(dec.osd0(syn, llr, hard), want), kind
+    # a batch that mixes them with syndromes that do come from errors
+    c = load_osd(tag)
+    mix_s = np.concatenate([syn[:5], c["syndromes"][:7], syn[5:9]])
+    mix_l = np.concatenate([llr[:5], c["llr"][:7], llr[5:9]])
+    mix_h = np.concatenate([hard[:5], c["hard"][:7], hard[5:9]])
+    mix_w = np.concatenate([want[:5], c["solution"][:7], want[5:9]])
+    for kind in (0, 1):
+        dec.set_option(_lib.OPT_OSD_BIG, kind)
+        assert np.array_equal(dec.osd0(mix_s, mix_l, mix_h), mix_w), kind
 
 
 def test_osd_beyond_the_lds_limit():

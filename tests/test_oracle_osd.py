@@ -26,3 +26,15 @@ def test_oracle_osd0_matches_reference(tag):
         # Distinct reliabilities: bit-exact by construction.  Tied |llr| (numpy's unstable
         # argsort decides the reference's order): equal in every committed vector as well.
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tag", ("72", "144", "288"))
+def test_oracle_osd0_on_syndromes_outside_the_column_space(tag):
+    """tests/golden/osd_inconsistent.npz: the reference's performOSD on random syndromes (none of them in the
+    column space).  Its output then depends on the row swaps of gf2_elimination (OSD.py:56-59), which the oracle
+    follows."""
+    d = np.load(os.path.join(os.path.dirname(GOLD), "osd_inconsistent.npz"))
+    H = d[f"{tag}/H"].astype(np.int64)
+    assert not d[f"{tag}/reproduces_syndrome"].any()
+    for s, l, h, want in zip(d[f"{tag}/syndromes"], d[f"{tag}/llr"], d[f"{tag}/hard"], d[f"{tag}/solution"]):
+        assert np.array_equal(oracle.osd0(H, s, l, h), want)
