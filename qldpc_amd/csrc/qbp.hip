@@ -1356,10 +1356,11 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
     const size_t wc_max = (n + 63) / 64 + 1;
     const size_t LDS_MAX = 160 * 1024 - 64;                          // (static __shared__ of the kernel: 64 bytes)
     const size_t qs = 8 * wc_max * 8;
+    const size_t act = m * 4;                                        // (row, D) list of a block's updates
     const size_t want_table = std::min<size_t>(96 * 1024, 256 * wc_max * 8);
-    size_t region0 = std::max(want_table, NP * 8), lds = region0 + qs + NP * 4 + ((n + 15) & ~(size_t)15);
+    size_t region0 = std::max(want_table, NP * 8), lds = region0 + qs + NP * 4 + ((n + 15) & ~(size_t)15) + act;
     Wk.keys_in_lds = 1;
-    if (lds > LDS_MAX) { Wk.keys_in_lds = 0; region0 = want_table; lds = region0 + qs; }
+    if (lds > LDS_MAX) { Wk.keys_in_lds = 0; region0 = want_table; lds = region0 + qs + act; }
     const bool blocked = !h->osd_ok && h->opt_osd_big != 2 && m <= 8192 && lds <= LDS_MAX && 2 * wc_max * 8 <= want_table;
     if (!h->osd_ok && !blocked) return osd_launch_swaps(h, O, max_items, s);
     if (redo) {
@@ -1374,7 +1375,7 @@ static int osd_launch(qbp_handle* h, qbp::OsdParams& O, long long max_items, hip
         // bit left -- after some 200 columns on the BP failures of the space-time matrices in the tests,
         // 1632 at most)
         Wk.k_first = h->opt_osd_big == 3 ? 24 : (int)std::min<size_t>(n, 2048);
-        if (lds + m * 4 <= LDS_MAX && h->opt_osd_big != 3) { Wk.lds_act = (int)lds; lds += m * 4; }
+        Wk.lds_act = (int)(lds - act);
         HIP_TRY(h->d_osd_next.reserve(1));
         HIP_TRY(hipMemsetAsync(h->d_osd_next.p, 0, 8, s));
         Wk.next = h->d_osd_next.p;

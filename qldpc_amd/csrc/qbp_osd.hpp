@@ -269,8 +269,7 @@ struct OsdBigWorkspace {
     int wc_max;                     // word planes of a full-width working copy: (n + 63) / 64 + 1
     int k_first;                    // sorted columns the first sweep keeps
     int lds_region0, lds_table;     // bytes: {keys | pos | table} region; the part of it the table may use
-    int lds_act;                    // byte offset of the list of rows a block updates (m words), 0: none -- every
-                                    // thread then updates its own rows
+    int lds_act;                    // byte offset of the list of rows a block updates (m words)
     unsigned long long* next;       // work counter (zero at launch): syndromes are handed out one at a time
 };
 
@@ -480,7 +479,7 @@ __global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, c
     const int tid = threadIdx.x, nt = 1024;
     const int m = P.m, n = P.n, NP = P.NP;
     char* const lds = reinterpret_cast<char*>(osd_smem);
-    unsigned* const act = Wk.lds_act ? reinterpret_cast<unsigned*>(lds + Wk.lds_act) : nullptr;
+    unsigned* const act = reinterpret_cast<unsigned*>(lds + Wk.lds_act);      // [m]: the rows a block updates
     u64* const table = reinterpret_cast<u64*>(lds);                        // region 0: keys -> pos -> table
     u64* const Qs = reinterpret_cast<u64*>(lds + Wk.lds_region0);          // [8][wc_max]
     u64* keys;
@@ -586,12 +585,11 @@ __global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, c
                 int T = 8;
                 while (T > 1 && ((k0 & (T - 1)) || ((size_t)nw << T) * 8 > (size_t)Wk.lds_table)) T >>= 1;
                 const int Tc = K - k0 < T ? K - k0 : T;
-                unsigned bt[RPT], D[RPT];
+                unsigned bd[RPT];             // bits 0-7: the row's bits in the block's columns, 8-15: its set D
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
                     const int r = tid + i * nt;
-                    bt[i] = r < m ? (unsigned)(At[(size_t)wk * m + r] >> sh) & ((1u << Tc) - 1u) : 0u;
-                    D[i] = 0u;
+                    bd[i] = r < m ? (unsigned)(At[(size_t)wk * m + r] >> sh) & ((1u << Tc) - 1u) : 0u;
                 }
                 int prow[8];
                 bool any = false;
@@ -605,10 +603,10 @@ __global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, c
                     unsigned cand = ~0u;
 #pragma unroll
                     for (int i = RPT - 1; i >= 0; --i) {
-                        const u64 b = __ballot(pc[i] < 0 && ((bt[i] >> j) & 1u));
+                        const u64 b = __ballot(pc[i] < 0 && ((bd[i] >> j) & 1u));
                         if (b) {
                             const int l = __builtin_ctzll(b);
-                            const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)((D[i] << 8) | bt[i]), l);
+                            const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)bd[i], l);
                             cand = ((unsigned)((tid & ~63) + l + i * nt) << 16) | v;
                         }
                     }
@@ -622,32 +620,33 @@ __global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, c
                     ++rank;
                     any = true;
                     const int p = (int)(key >> 16);
-                    const unsigned Bp = key & 0xffu, cs = (1u << j) | ((key >> 8) & 0xffu);
+                    // (the pivot's byte into the low bits, pivot j plus the pivot's own pending set into D)
+                    const unsigned upd = (key & 0xffffu) | (0x100u << j);
                     prow[j] = p;
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
                         const int r = tid + i * nt;
                         if (r == p) pc[i] = idx[k0 + j];
-                        else if ((bt[i] >> j) & 1u) { bt[i] ^= Bp; D[i] ^= cs; }            // :63-68, on the bytes
+                        else if ((bd[i] >> j) & 1u) bd[i] ^= upd;                           // :63-68, on the bytes
                     }
                 }
                 k0 += T;
                 OSD_T(3);
                 if (!any) continue;
                 unsigned* const nact = &s_nact[blk_ctr & 1u];
-                if (act) {
+                {
                     // the rows this block changes, as (row, D) words in LDS: the update below is spread over all
                     // threads (a block touches some 40 of the rows of a sparse matrix)
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
-                        const bool a = D[i] != 0u;
+                        const bool a = (bd[i] >> 8) != 0u;
                         const u64 b = __ballot(a);
                         if (b) {
                             unsigned base = 0;
                             if ((tid & 63) == 0) base = atomicAdd(nact, (unsigned)__builtin_popcountll(b));
                             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                             if (a) act[base + (unsigned)__builtin_popcountll(b & ((1ull << (tid & 63)) - 1ull))] =
-                                       ((unsigned)(tid + i * nt) << 8) | D[i];
+                                       ((unsigned)(tid + i * nt) << 8) | (bd[i] >> 8);
                         }
                     }
                     if (tid == 0) s_nact[(blk_ctr + 1u) & 1u] = 0u;       // (the next block's counter: idle now)
@@ -693,10 +692,10 @@ __global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, c
                 }
                 __syncthreads();
                 OSD_T(5);
-                if (act) {
+                {
 #pragma unroll
                     for (int i = 0; i < RPT; ++i)
-                        if (D[i]) sb ^= ((unsigned)table[(size_t)D[i] * nw + nw - 1] & 1u) << i;
+                        if (bd[i] >> 8) sb ^= ((unsigned)table[(size_t)(bd[i] >> 8) * nw + nw - 1] & 1u) << i;
                     const int na = (int)*nact, items = na * nw;
                     OSD_STAT(1, tid == 0 ? na : 0); OSD_STAT(2, tid == 0 ? items : 0);
                     for (int it0 = tid; it0 < items; it0 += 4 * nt) {
@@ -716,26 +715,6 @@ __global__ __launch_bounds__(1024) void osd0_blocked_kernel(const OsdParams P, c
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             if (it0 + q * nt < items) *a[q] = v[q] ^ t[q];
-                    }
-                } else
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = tid + i * nt;
-                    if (D[i] == 0u) continue;                         // (r >= m: never set)
-                    OSD_STAT(1, 1); OSD_STAT(2, nw);
-                    const u64* const trow = table + (size_t)D[i] * nw;
-                    u64* const arow = At + (size_t)wk * m + r;
-                    sb ^= ((unsigned)trow[nw - 1] & 1u) << i;
-                    // (eight loads in flight, then eight stores: the compiler cannot tell that the planes do not
-                    // alias and would otherwise wait for every store before the next load)
-                    for (int w0 = 0; w0 < nw; w0 += 8) {
-                        u64 v[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (w0 + q < nw) v[q] = arow[(size_t)(w0 + q) * m];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (w0 + q < nw) arow[(size_t)(w0 + q) * m] = v[q] ^ trow[w0 + q];
                     }
                 }
                 // (the barrier at the top of the next block comes before anyone reads a row again or

@@ -214,6 +214,39 @@ def test_osd_beyond_the_lds_limit():
         assert np.array_equal(dec.osd0(syn[f], llr[f], hard[f]), got), kind
 
 
+def test_osd_on_5184_rows_sort_keys_in_global_memory():
+    """Six copies of the 864 x 2592 space-time matrix of [[144,12,12]] (5184 x 15552): eight rows per thread in
+    the blocked kernel, and n > 8192 puts the sort keys and the sorted order into the global workspace.  Same
+    solutions as the one-pivot-at-a-time kernel; every solution reproduces its syndrome."""
+    from scipy.sparse import block_diag, csr_matrix
+    H144 = codes.load_code("[[144, 12, 12]]").Hx
+    mm = H144.shape[0]
+    T = 12
+    st = csr_matrix(np.hstack([np.kron(np.eye(T, dtype=np.int64), H144),
+                               (np.eye(mm * T, dtype=np.int64) + np.eye(mm * T, k=-mm, dtype=np.int64)) % 2]))
+    H = block_diag([st] * 6).tocsr()
+    dec = _fresh_decoder(H)
+    m, n = H.shape
+    rng = np.random.default_rng(9)
+    p = 0.03
+    err = csr_matrix((rng.random((24, n)) < p).astype(np.int64))
+    syn = np.asarray((err @ H.T).todense() % 2).astype(np.uint8)
+    hard, conv, iters, llr = dec.decode(syn, mc.prior_of(p, n), 12)
+    f = np.flatnonzero(~conv)[:12]
+    assert len(f) >= 3
+    got = dec.osd0(syn[f], llr[f], hard[f])
+    back = np.asarray((csr_matrix(got.astype(np.int64)) @ H.T).todense() % 2).astype(np.uint8)
+    assert np.array_equal(back, syn[f])
+    dec.set_option(_lib.OPT_OSD_BIG, 2)
+    assert np.array_equal(dec.osd0(syn[f], llr[f], hard[f]), got)
+    # ... and a random syndrome (outside the column space or not: the redo pass decides), against the same kernel
+    dec.set_option(_lib.OPT_OSD_BIG, 0)
+    s2 = (rng.random((2, m)) < 0.5).astype(np.uint8)
+    a = dec.osd0(s2, llr[f[:2]], hard[f[:2]])
+    dec.set_option(_lib.OPT_OSD_BIG, 2)
+    assert np.array_equal(dec.osd0(s2, llr[f[:2]], hard[f[:2]]), a)
+
+
 def test_mc_osd_on_an_irregular_matrix_equals_oracle():
     """BP + OSD-0 Monte-Carlo where the general-H kernel is the only BP kernel ([[72,12,6]] plus one
     check of weight 12): counters equal the oracle pipeline's, with either OSD kernel."""
