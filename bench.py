@@ -22,7 +22,8 @@ still those of the first converged iteration).  Everything else in the line is m
 * ``hbm_effective``  SURVEY 8(d)'s algorithmic bytes over the kernel time (exceeds the HBM peak: the
                      messages it counts never leave the CU) -- kept as the north star's own yardstick.
 * ``early_exit``     reference semantics (mode M1); ``stress_p010`` forced-50 on a p = 0.10 batch BP
-                     cannot decode (M2 stress of SURVEY 8(d)); ``sustained`` >= 10 s of back-to-back
+                     cannot decode (M2 stress of SURVEY 8(d)); ``fast_math_flag`` the same launch with the opt-in
+                     QBP_FLAG_FAST_MATH (not bit-exact: never the headline); ``sustained`` >= 10 s of back-to-back
                      forced-50 launches and the shader clock right after; ``hbm_streamed_variant`` the
                      one-lane-per-syndrome kernel whose messages do go through HBM; ``dropin_api`` the
                      reference's own calling pattern (paperResults_GPU.py:95-144) through the Python
@@ -423,7 +424,7 @@ def main():
                  "kernel_share_of_step_per_rank": [float(x) / ms_step for x in km.tolist()]}
 
     # ---- M1: reference semantics (early exit) -----------------------------------------------
-    early = stress = sustained = None
+    early = stress = sustained = fast_math = None
     if full:
         wall1, kernel_ms1, counts1 = timed(0, args.steps, 1)
         bytes1 = algorithmic_bytes(E, m, n, counts1[1] / world + B, B)
@@ -441,6 +442,14 @@ def main():
                   "ratio_to_headline_kernel_ms": kernel_ms10 / kernel_ms,
                   "note": "same launch on a batch BP cannot decode: no data-dependent shortcut in forced mode"}
         del syn10
+        # ---- QBP_FLAG_FAST_MATH: the opt-in approximate tanh / arctanh (NOT the headline: LLRs then differ from
+        # the reference's in the last digits; decisions identical on every stored vector) ----------------
+        wallf, kernel_msf, countsf = timed(_lib.FLAG_FORCE_FULL | _lib.FLAG_FAST_MATH, max(3, args.steps // 4), 1)
+        fast_math = {"value": world * B * max(3, args.steps // 4) / wallf, "unit": "syndromes/s",
+                     "kernel_ms": kernel_msf, "ratio_to_headline": kernel_ms / kernel_msf,
+                     "converged_fraction": countsf[0] / (world * B),
+                     "note": "forced-50 with QBP_FLAG_FAST_MATH (round 2's 2.3 / 1.2-ulp functions); "
+                             "tests/test_gpu_fast_math.py states what it keeps and what it gives up"}
         # ---- sustained: back-to-back forced-50 launches for >= N seconds -------------------------
         if args.sustained_seconds > 0:
             n_launch = max(args.steps, int(np.ceil(args.sustained_seconds / (kernel_ms * 1e-3))))
@@ -570,6 +579,7 @@ def main():
             "multi_gpu": multi,
             "early_exit": early,
             "stress_p010": stress,
+            "fast_math_flag": fast_math,
             "sustained": sustained,
             "hbm_streamed_variant": streamed,
             "other_configs": others,

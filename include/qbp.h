@@ -73,6 +73,14 @@ enum {
                                  works on C-ordered (B, m, n) arrays whatever H is: default order.
                                  QBP_E_UNSUPPORTED when some column's association is not a left-to-right sum
                                  of a reordering of its entries (possible from 4 entries per column on). */
+    QBP_FLAG_FAST_MATH = 32u, /* opt-in, on-chip kernel only (matrices of the (6,3) / (8,4) shape classes; the other
+                                 kernels ignore it): tanh and arctanh by rational / polynomial approximations of
+                                 2.3 and 1.2 ulp (round 2's functions) instead of numpy's own two routines.  Posterior
+                                 LLRs then follow numpy's to ~1e-6 relative while a syndrome converges early and
+                                 drift apart like any other libm's on late convergers (tests/test_gpu_fast_math.py
+                                 prints the table); hard decision, converged flag and iteration were identical
+                                 to the reference's on every stored vector.  +28 % throughput on forced-50
+                                 [[288,12,18]].  Default (flag clear): every output bit equal to the reference's. */
     QBP_FLAG_DENSE_F_COLSUM_ITER0 = 16u /* ... at iteration 0 only: the damped variants (rework/decoding.py:5,
                                  :131) on a Fortran-ordered H of fewer than 32768 entries -- `Q_old = Q.copy()`
                                  is C-ordered and C order wins in `damping * Q_new + (1 - damping) * Q_old` (:65,

@@ -23,6 +23,7 @@ FLAG_OSD0 = 2
 FLAG_PAIRWISE_COLSUM = 4     # np.sum order of the loop form (beliefPropagation.py:68)
 FLAG_DENSE_F_COLSUM = 8      # np.sum(R, axis=0) order of the dense forms on a Fortran-ordered H (include/qbp.h)
 FLAG_DENSE_F_COLSUM_ITER0 = 16   # ... at iteration 0 only (damped variants, F-ordered H below 256 KiB)
+FLAG_FAST_MATH = 32          # opt-in: round 2's tanh / arctanh approximations on the on-chip kernel (include/qbp.h)
 MC_OSD_MAX_TRIALS = 1 << 20
 NUM_COUNTERS = 12
 COUNTER_NAMES = ("trials", "logical_error", "BPs_fault", "BPs_miscorrected", "incorrectable",

@@ -995,7 +995,8 @@ try {
     // >= B -- and the memset node is skipped (3 us of a 30 us single-syndrome call).
     if (B > (long long)cfg.grid * cfg.S)
         HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(qbp::launch_fused(false, variant, P, cfg, s));
+    HIP_TRY((flags & QBP_FLAG_FAST_MATH) ? qbp::launch_fused_fast_math(false, variant, P, cfg, s)
+                                         : qbp::launch_fused(false, variant, P, cfg, s));
     return QBP_OK;
 }
 QBP_ABI_CATCH
@@ -1524,7 +1525,8 @@ static int mc_run_impl(qbp_handle* h, const uint8_t* Lx_host, int32_t k, int32_t
         P.fail_hard = h->d_fail_hard.p; P.fail_err = h->d_fail_err.p;
     }
     HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(qbp::launch_fused(true, variant, P, cfg, s));
+    HIP_TRY((flags & QBP_FLAG_FAST_MATH) ? qbp::launch_fused_fast_math(true, variant, P, cfg, s)
+                                         : qbp::launch_fused(true, variant, P, cfg, s));
     h->last_kernel = 1;
     if (osd) {
         rc = osd_pass();

@@ -36,6 +36,7 @@ struct LaunchCfg {
 
 // qbp_tu_fused.hip
 hipError_t launch_fused(bool mc, int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s);
+hipError_t launch_fused_fast_math(bool mc, int variant, const FusedParams& P, const LaunchCfg& cfg, hipStream_t s);
 hipError_t launch_debug_math(int kind, const double* x, double* y, long long count, hipStream_t s);
 hipError_t launch_mc_sample(uint8_t* errors, int n, long long T, long long trial_begin, int draws,
                             unsigned long long seed, unsigned threshold, hipStream_t s);

@@ -1,5 +1,12 @@
 // libqbp.so, translation unit of the on-chip kernel (qbp_kernels.hpp): its 27 instantiations.
+// Compiled twice: as is (numpy's tanh / arctanh: the default), and with -DQBP_FAST_TU -DQBP_MATH_FAST=1 under
+// other names (QBP_FLAG_FAST_MATH: round 2's approximations); each build is a code object of its own.
+#ifdef QBP_FAST_TU
+#define bp_fused_kernel bp_fused_kernel_fast_math
+#define launch_fused launch_fused_fast_math
+#else
 #define QBP_DEFINE_KERNELS 1
+#endif
 #include <hip/hip_runtime.h>
 
 #include "../../include/qbp.h"
@@ -62,6 +69,7 @@ hipError_t launch_fused(bool mc, int variant, const FusedParams& P, const Launch
     return mc ? launch_variant<true>(variant, P, cfg, s) : launch_variant<false>(variant, P, cfg, s);
 }
 
+#ifndef QBP_FAST_TU
 hipError_t launch_debug_math(int kind, const double* x, double* y, long long count, hipStream_t s)
 {
     const int threads = 256;
@@ -79,5 +87,6 @@ hipError_t launch_mc_sample(uint8_t* errors, int n, long long T, long long trial
                        errors, n, T, trial_begin, draws, seed, threshold);
     return hipGetLastError();
 }
+#endif  // QBP_FAST_TU
 
 }  // namespace qbp
