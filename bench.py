@@ -424,6 +424,46 @@ def main():
                  "kernel_share_of_step_per_rank": [float(x) / ms_step for x in km.tolist()]}
 
     # ---- M1: reference semantics (early exit) -----------------------------------------------
+    # ---- the HBM-streamed design point (qbp_stream.hpp), same workload, forced 50 ----------------
+    streamed = None
+    if full and world == 1:
+        # one lane per syndrome needs >= 256 CUs x 16 waves x 64 lanes to fill the chip: its own batch
+        Bs = 262144
+        reps = -(-Bs // B)
+        syn_s = syndromes.repeat((reps, 1))[:Bs].contiguous()
+        hard_s = torch.empty((Bs, n), dtype=torch.uint8, device=dev)
+        conv_s = torch.empty((Bs,), dtype=torch.uint8, device=dev)
+        iters_s = torch.empty((Bs,), dtype=torch.int32, device=dev)
+        llr_s = torch.empty((Bs, n), dtype=torch.float64, device=dev)
+        dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_STREAM)
+        ms_s = []
+        for i in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            dec.decode_device(syn_s.data_ptr(), prior.data_ptr(), Bs, MAX_ITER, _lib.SUM_PRODUCT, 1.0, 1.0,
+                              20.0, _lib.FLAG_FORCE_FULL, hard_s.data_ptr(), conv_s.data_ptr(),
+                              iters_s.data_ptr(), llr_s.data_ptr(), stream.cuda_stream)
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            if i:
+                ms_s.append(a.elapsed_time(b))
+        dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
+        kernel_ms_s = float(np.mean(ms_s))
+        step(_lib.FLAG_FORCE_FULL)
+        torch.cuda.synchronize(dev)
+        same = bool(torch.equal(hard_s[:B], hard) and torch.equal(iters_s[:B], iters))
+        del syn_s, hard_s, conv_s, iters_s, llr_s
+        bytes_s = algorithmic_bytes(E, m, n, Bs * MAX_ITER, Bs)
+        ach_s = bytes_s / (kernel_ms_s * 1e-3)
+        streamed = {"kernel": "qbp::bp_stream_kernel<0>", "syndromes_per_launch": Bs,
+                    "value": Bs / (kernel_ms_s * 1e-3), "unit": "syndromes/s per GPU",
+                    "kernel_ms": kernel_ms_s, "same_results_as_default_kernel": same,
+                    "roofline": {"bound": "hbm", "achieved": ach_s / 1e9, "peak": HBM_PEAK / 1e9,
+                                 "unit": "GB/s", "frac": ach_s / HBM_PEAK, **stream_traffic()},
+                    "note": "one lane per syndrome, messages streamed through HBM ([edge][syndrome] SoA): "
+                            "here the algorithmic bytes ARE the physical traffic (PMC: profiles/); not the "
+                            "default kernel"}
+
     early = stress = sustained = fast_math = None
     if full:
         wall1, kernel_ms1, counts1 = timed(0, args.steps, 1)
@@ -482,46 +522,6 @@ def main():
                          "rank0_rate_by_tenth": [float(x) for x in seg],
                          "shader_clock_GHz_during": [x for x in sclk if x],
                          "shader_clock_GHz_right_after": clock_s}
-
-    # ---- the HBM-streamed design point (qbp_stream.hpp), same workload, forced 50 ----------------
-    streamed = None
-    if full and world == 1:
-        # one lane per syndrome needs >= 256 CUs x 16 waves x 64 lanes to fill the chip: its own batch
-        Bs = 262144
-        reps = -(-Bs // B)
-        syn_s = syndromes.repeat((reps, 1))[:Bs].contiguous()
-        hard_s = torch.empty((Bs, n), dtype=torch.uint8, device=dev)
-        conv_s = torch.empty((Bs,), dtype=torch.uint8, device=dev)
-        iters_s = torch.empty((Bs,), dtype=torch.int32, device=dev)
-        llr_s = torch.empty((Bs, n), dtype=torch.float64, device=dev)
-        dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_STREAM)
-        ms_s = []
-        for i in range(4):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            dec.decode_device(syn_s.data_ptr(), prior.data_ptr(), Bs, MAX_ITER, _lib.SUM_PRODUCT, 1.0, 1.0,
-                              20.0, _lib.FLAG_FORCE_FULL, hard_s.data_ptr(), conv_s.data_ptr(),
-                              iters_s.data_ptr(), llr_s.data_ptr(), stream.cuda_stream)
-            b.record(stream)
-            torch.cuda.synchronize(dev)
-            if i:
-                ms_s.append(a.elapsed_time(b))
-        dec.set_option(_lib.OPT_KERNEL, _lib.KERNEL_AUTO)
-        kernel_ms_s = float(np.mean(ms_s))
-        step(_lib.FLAG_FORCE_FULL)
-        torch.cuda.synchronize(dev)
-        same = bool(torch.equal(hard_s[:B], hard) and torch.equal(iters_s[:B], iters))
-        del syn_s, hard_s, conv_s, iters_s, llr_s
-        bytes_s = algorithmic_bytes(E, m, n, Bs * MAX_ITER, Bs)
-        ach_s = bytes_s / (kernel_ms_s * 1e-3)
-        streamed = {"kernel": "qbp::bp_stream_kernel<0>", "syndromes_per_launch": Bs,
-                    "value": Bs / (kernel_ms_s * 1e-3), "unit": "syndromes/s per GPU",
-                    "kernel_ms": kernel_ms_s, "same_results_as_default_kernel": same,
-                    "roofline": {"bound": "hbm", "achieved": ach_s / 1e9, "peak": HBM_PEAK / 1e9,
-                                 "unit": "GB/s", "frac": ach_s / HBM_PEAK, "traffic": None},
-                    "note": "one lane per syndrome, messages streamed through HBM ([edge][syndrome] SoA): "
-                            "here the algorithmic bytes ARE the physical traffic (PMC: profiles/); not the "
-                            "default kernel"}
 
     # ---- the reference's calling pattern through the drop-in API (host arrays, PCIe included) -----
     dropin = None
@@ -595,6 +595,21 @@ def main():
 
 
 PMC_LEGS = os.path.join(ROOT, "profiles", "r03_pmc_legs.json")       # tools/profile_r03.sh, tools/bench_legs.py --once
+
+
+def stream_traffic():
+    """HBM bytes per launch of the streaming kernel from the committed PMC summary (tools/profile_stream.sh: same
+    script, same batch; FETCH_SIZE x 2 for gfx950 + WRITE_SIZE, passes of their own)."""
+    path = os.path.join(ROOT, "profiles", "r03_stream_pmc_summary.json")
+    try:
+        d = json.load(open(path))
+        return {"traffic": d["hbm_read_bytes_x2"] + d["hbm_write_bytes"],
+                "traffic_detail": {"file": os.path.relpath(path, ROOT), "read_bytes_x2_gfx950": d["hbm_read_bytes_x2"],
+                                   "write_bytes": d["hbm_write_bytes"],
+                                   "physical_over_algorithmic": d["physical_over_algorithmic"],
+                                   "physical_GBps_in_that_run": d["physical_GBps"]}}
+    except Exception as ex:
+        return {"traffic": None, "traffic_error": f"{type(ex).__name__}: {ex}"}
 
 
 def other_config_legs(device, num_cu):
