@@ -140,8 +140,10 @@ __host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool ld
 // Check update of one row held in registers: q[D] -> r[D]   (beliefPropagation.py:114-126 /
 // rework/decoding.py:28-56).  `scale` is false for the alpha_estimation dump of the damped variant
 // (rework/decoding.py:168-169 returns R before the alpha scaling).
-template <int VARIANT, int D>
-__device__ __forceinline__ void generic_row_update(const double (&q)[D], double (&r)[D], unsigned sbit,
+// `put(j, value)` takes message j as soon as it exists (eight finished messages waiting for their stores are
+// sixteen registers the wide rows do not have).
+template <int VARIANT, int D, typename Put>
+__device__ __forceinline__ void generic_row_update(const double (&q)[D], const Put& put, unsigned sbit,
                                                    double alpha, bool scale, NpT np_tab)
 {
     if constexpr (VARIANT == 2) {
@@ -168,7 +170,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
         for (int j = 0; j < D; ++j) {
             const double sg = q[j] < 0.0 ? -1.0 : 1.0;
             const double mag = (__builtin_fabs(q[j]) == min1) ? min2 : min1;
-            r[j] = (as * (sprod * sg)) * mag;
+            put(j, (as * (sprod * sg)) * mag);
         }
     } else {
         double t[D];
@@ -189,7 +191,7 @@ __device__ __forceinline__ void generic_row_update(const double (&q)[D], double 
         for (int j = 0; j < D; ++j) {
             const double ts = t[j];
             const double x = check_message<VARIANT>(div_nr(prod, ts), sbit, np_tab);     // :123-126
-            r[j] = (VARIANT == 1 && scale) ? x * alpha : x;
+            put(j, (VARIANT == 1 && scale) ? x * alpha : x);
             QBP_EDGE_FENCE();
         }
     }
@@ -544,10 +546,10 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         const int w = P.row_off[DD] + i;                                           \
                         const unsigned sbit = (synw[w >> 5] >> (w & 31)) & 1u;                     \
                         const int base = P.row_base[DD] + i;                                       \
-                        double q[DD], r[DD];                                                       \
+                        double q[DD];                                                              \
                         _Pragma("unroll") for (int j = 0; j < DD; ++j) q[j] = QBP_GEN_QLOAD(base + j * cnt);   \
-                        generic_row_update<VARIANT, DD>(q, r, sbit, P.alpha, scale, np_tab);               \
-                        _Pragma("unroll") for (int j = 0; j < DD; ++j) Rstore(base + j * cnt, r[j]);   \
+                        generic_row_update<VARIANT, DD>(q, [&](int j, double v) { Rstore(base + j * cnt, v); }, \
+                                                        sbit, P.alpha, scale, np_tab);                     \
                     }                                                                              \
                 } break;
                 switch (D) {
