@@ -578,16 +578,17 @@ int resolve_column_order(qbp_handle* h, unsigned& flags, const double* host_prio
 //   workgroups per CU: as many as fit 16 wavefronts (the kernel's 128-register budget) and the LDS.
 struct GenericGeom { bool lds_msgs, lds_tables; int mem, r_split, threads, per_cu, grid; size_t lds; };
 
-static GenericGeom generic_geometry(const qbp_handle* h, long long B)
+// inplace: sum-product without damping keeps one message array (qbp_generic.hpp): 8 E bytes instead of 16 E
+static GenericGeom generic_geometry(const qbp_handle* h, long long B, bool inplace)
 {
     GenericGeom g{};
     const int E1 = std::max(h->E, 1);
     constexpr size_t LDS_MAX = (size_t)160 * 1024;
-    g.lds_msgs = qbp::generic_lds_bytes(h->m, E1, h->n, true, false) <= LDS_MAX && h->opt_mem == 0;
+    g.lds_msgs = qbp::generic_lds_bytes(h->m, E1, h->n, true, false, 0, inplace) <= LDS_MAX && h->opt_mem == 0;
     // the variable step's tables (prior, message positions) in LDS too when one workgroup per CU is
     // the geometry anyway and they fit beside (or instead of) the messages
     g.lds_tables = false;
-    g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, false);
+    g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, false, 0, inplace);
     const int short_rows = std::max(1, h->row_off[qbp::GENERIC_MAX_ROW_CLASS + 1] - h->row_off[1]);
     const int work = std::max(h->rpad_off[qbp::GENERIC_MAX_ROW_CLASS + 1], 64);    // padded work items
     const int passes = (work + 1023) / 1024;
@@ -619,9 +620,9 @@ static GenericGeom generic_geometry(const qbp_handle* h, long long B)
         g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, false, false, g.r_split);
     }
     if (per_cu == 1 && !h->opt_no_lds_tables && g.mem != qbp::GENERIC_MEM_SPLIT &&
-        qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split) <= LDS_MAX) {
+        qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split, inplace) <= LDS_MAX) {
         g.lds_tables = true;
-        g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split);
+        g.lds = qbp::generic_lds_bytes(h->m, E1, h->n, g.lds_msgs, true, g.r_split, inplace);
     }
     g.threads = threads; g.per_cu = per_cu;
     g.grid = (int)std::max<long long>(1, std::min<long long>(B, (long long)h->num_cu * per_cu));
@@ -654,14 +655,16 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
         return QBP_OK;
     }
     const size_t E = (size_t)std::max(h->E, 1), n = (size_t)h->n;
-    const GenericGeom g = generic_geometry(h, B);
+    const bool inplace = QBP_GENERIC_INPLACE != 0 && variant == QBP_SUM_PRODUCT;
+    const GenericGeom g = generic_geometry(h, B, inplace);
     if (g.lds > (size_t)160 * 1024)
         return fail(QBP_E_UNSUPPORTED, "m = %d checks need %zu B of LDS for the parity bits (limit 160 KiB)",
                     h->m, g.lds);
     if (!g.lds_msgs) {
-        HIP_TRY(h->d_wsQ.reserve((size_t)g.grid * E));
+        if (!inplace) HIP_TRY(h->d_wsQ.reserve((size_t)g.grid * E));
         HIP_TRY(h->d_wsR.reserve((size_t)g.grid * E));
     }
+    if (inplace) HIP_TRY(h->d_wsV.reserve((size_t)g.grid * n));
     HIP_TRY(h->d_prior_sorted.reserve(n));
     HIP_TRY(qbp::launch_permute_prior(d_prior, h->d_svar.p, h->d_prior_sorted.p, (int)n, s));
     qbp::GenericParams G{};
@@ -691,7 +694,7 @@ static int generic_launch(qbp_handle* h, const uint8_t* d_syndromes, const doubl
     G.syndromes = d_syndromes; G.B = B; G.max_iter = max_iter; G.flags = flags;
     G.alpha = alpha; G.damping = damping; G.clip_llr = clip_llr;
     G.hard = d_hard; G.converged = d_converged; G.iters = d_iters; G.llr = d_llr;
-    G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p;
+    G.wsQ = h->d_wsQ.p; G.wsR = h->d_wsR.p; G.wsV = h->d_wsV.p;
     G.work_counter = h->d_work_counter.p;
     if (B > (int64_t)g.grid)     // (else every index it can yield is >= B whatever it holds)
         HIP_TRY(hipMemsetAsync(h->d_work_counter.p, 0, sizeof(unsigned long long), s));

@@ -19,6 +19,13 @@
 //                  that started as the syndrome, and moves a counter of unsatisfied checks;
 //   -- barrier B --
 //   the counter is zero <=> converged.
+// Sum-product without damping (VARIANT 0) keeps ONE array of E messages, updated in place: a slot holds the
+// variable->check message before the check step and the check->variable message after it (a check reads its
+// row's slots, then writes them; a variable reads its column's slots, then writes them).  Half the LDS -- or,
+// for a matrix whose 2E messages did not fit (2592 x 7776: E doubles are 164.7 KB), nearly all traffic of the
+// variable step in LDS instead of scattered 8-byte stores to L2.  The posterior values of the current
+// iteration then go to a per-workgroup array V[n] (coalesced, sorted variable order) for the emission.
+// The damped variants need last iteration's Q beside R: two arrays, as before.
 // Posterior values and hard decisions are not stored per iteration: when a syndrome is emitted
 // (first convergence, or the iteration limit) they are recomputed from R, which is still that
 // iteration's.  Every product / sum runs sequentially in the reference's order (ascending column
@@ -92,8 +99,9 @@ struct GenericParams {
     uint8_t* converged;
     int32_t* iters;
     double* llr;
-    double* wsQ;                // [grid][E]   (messages in global memory only)
+    double* wsQ;                // [grid][E]   (messages in global memory only; not with the in-place update)
     double* wsR;                // [grid][E]
+    double* wsV;                // [grid][n]   in-place update (VARIANT 0): posterior values of the current iteration
     // message dump (alpha_estimation=True of rework/decoding.py:58-59 and :168-169): after the check
     // step of iteration dump_iter, write the check->variable messages of every edge (CSR order)
     // to dump_R[b][E] and stop decoding that syndrome.  dump_div divides (min-sum: alpha).
@@ -130,10 +138,10 @@ __host__ __device__ inline size_t generic_lds_words(int m)
     return (((3 * mw + 2 + 1) & ~(size_t)1) + 4 + NUM_COUNTERS + 2 + 1) & ~(size_t)1;
 }
 __host__ __device__ inline size_t generic_lds_bytes(int m, int E, int n, bool lds_msgs, bool lds_tables,
-                                                    int r_split = 0)
+                                                    int r_split = 0, bool inplace = false)
 {
     return (size_t)NP_LDS_BYTES +      // tables of tanh / arctanh (qbp_math.hpp), at the start
-           (lds_msgs ? (size_t)16 * (size_t)E : (size_t)8 * (size_t)r_split) + generic_lds_words(m) * 4 +
+           (lds_msgs ? (size_t)(inplace ? 8 : 16) * (size_t)E : (size_t)8 * (size_t)r_split) + generic_lds_words(m) * 4 +
            (lds_tables ? (size_t)8 * (size_t)n + (size_t)4 * (size_t)E : 0);
 }
 
@@ -261,11 +269,14 @@ __global__ void generic_permute_prior(const double* prior, const int32_t* svar, 
 //                       are 896 bytes more than the LDS holds).  R is then reached through flat
 //                       pointers picked per access.
 constexpr int GENERIC_MEM_GLOBAL = 0, GENERIC_MEM_LDS = 1, GENERIC_MEM_SPLIT = 2;
+#ifndef QBP_GENERIC_INPLACE      /* 0: two message arrays for every variant (A/B, tests of the host's sizing) */
+#define QBP_GENERIC_INPLACE 1
+#endif
 
 #ifdef QBP_GEN_FAKE_Q       /* timing-only build: the check step's Q loads come from LDS (wrong results) */
 #define QBP_GEN_QLOAD(pos) fake_q(pos)
 #else
-#define QBP_GEN_QLOAD(pos) Q[pos]
+#define QBP_GEN_QLOAD(pos) Qload(pos)
 #endif
 
 template <int VARIANT, bool MC, int MEM>
@@ -281,15 +292,17 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
     const int lane = tid & 63;
     const int m = P.m, n = P.n, E = P.E;
     constexpr int RC = GENERIC_MAX_ROW_CLASS, CC = GENERIC_MAX_COL_CLASS;
+    constexpr bool INPLACE = VARIANT == 0 && QBP_GENERIC_INPLACE != 0;     // one message array (see the top)
     double* Q;
     double* R;
     unsigned* words;
     if constexpr (LDSMSG) {
-        Q = gsm; R = gsm + E; words = reinterpret_cast<unsigned*>(gsm + 2 * (size_t)E);
+        Q = gsm; R = INPLACE ? gsm : gsm + E; words = reinterpret_cast<unsigned*>(gsm + (INPLACE ? 1 : 2) * (size_t)E);
     } else {
-        Q = P.wsQ + (size_t)blockIdx.x * E; R = P.wsR + (size_t)blockIdx.x * E;
+        R = P.wsR + (size_t)blockIdx.x * E; Q = INPLACE ? R : P.wsQ + (size_t)blockIdx.x * E;
         words = reinterpret_cast<unsigned*>(gsm + (MEM == GENERIC_MEM_SPLIT ? P.r_split : 0));
     }
+    double* const V = INPLACE ? P.wsV + (size_t)blockIdx.x * n : nullptr;
     // check->variable message at layout position `pos` (split mode: an LDS access or a global one,
     // under the lanes' own masks -- whole wavefronts on one side skip the other)
     auto Rload = [&](int pos) -> double {
@@ -316,6 +329,13 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
         } else {
             R[pos] = v;
         }
+    };
+    // variable->check message at `pos`: the same slot as R's with the in-place update
+    auto Qload = [&](int pos) -> double {
+        if constexpr (INPLACE) return Rload(pos); else return Q[pos];
+    };
+    auto Qstore = [&](int pos, double v) {
+        if constexpr (INPLACE) Rstore(pos, v); else Q[pos] = v;
     };
     const int mw = (m + 31) >> 5;
     unsigned* const synw = words;                   // [mw] syndrome bits, sorted check order
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
     auto q_update = [&](int o, double val, double r) {
         const double qn = val - r;
         if constexpr (VARIANT == 0) {
-            Q[o] = qn;
+            Qstore(o, qn);
         } else {
             const double q = P.damping * qn + one_minus_damping * Q[o];
             const double y = q < -P.clip_llr ? -P.clip_llr : q;     // np.clip, NaN stays NaN
@@ -426,11 +446,11 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             generic_col_class(P, x, D, cnt, o);
             const int32_t* const pos = vpos_t + o;
             const double pv = prior_t[x];
-            for (int j = 0; j < D; ++j) Q[pos[(size_t)j * cnt]] = pv;
+            for (int j = 0; j < D; ++j) Qstore(pos[(size_t)j * cnt], pv);
         }
         for (int i = tid; i < n_lcol; i += nt) {
             const double pv = prior_t[first_lcol + i];
-            for (int k = P.lcol_ptr[i]; k < P.lcol_ptr[i + 1]; ++k) Q[vpos_t[k]] = pv;
+            for (int k = P.lcol_ptr[i]; k < P.lcol_ptr[i + 1]; ++k) Qstore(vpos_t[k], pv);
         }
         __syncthreads();
         const int syn_weight = unsat[0];      // unsatisfied checks of the all-zero candidate
@@ -466,6 +486,8 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                 double val;
                 if (x < P.col_off[1]) {
                     val = prior_t[x];                        // isolated variable
+                } else if (INPLACE) {
+                    val = V[x];                              // (the slots hold Q by now)
                 } else if (x < first_lcol) {
                     int D, cnt, o;
                     generic_col_class(P, x, D, cnt, o);
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             if (n_long > 0) {                                           // uniform
                 double* const L = P.wsL + (size_t)blockIdx.x * 3 * n_long;
                 if constexpr (VARIANT != 2) {
-                    for (int k = tid; k < n_ledges; k += nt) Rstore(lbase + k, tanh_half_msg<VARIANT>(Q[lbase + k], np_tab));
+                    for (int k = tid; k < n_ledges; k += nt) Rstore(lbase + k, tanh_half_msg<VARIANT>(Qload(lbase + k), np_tab));
                     __syncthreads();
                 }
                 for (int i = tid; i < n_long; i += nt) {
@@ -670,6 +692,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
                         double s = r[0];                                                           \
                         _Pragma("unroll") for (int j = 1; j < DD; ++j) s = s + r[j];               \
                         const double val = s + prior_t[P.col_off[DD] + i];                         \
+                        if constexpr (INPLACE) V[P.col_off[DD] + i] = val;                         \
                         if (!frozen && val < 0.0) {                                                \
                             _Pragma("unroll") for (int j = 0; j < DD; ++j) flip(vr[base + j * cnt]); \
                         }                                                                          \
@@ -686,6 +709,7 @@ __global__ __launch_bounds__(1024) void bp_generic_kernel(const GenericParams P)
             for (int i = tid; i < n_lcol; i += nt) {
                 const int32_t* pos; int deg;
                 const double val = long_column_value(i, pos, deg);
+                if constexpr (INPLACE) V[first_lcol + i] = val;
                 if (!frozen && val < 0.0) {
                     const int32_t* const row = vr + (pos - vp);
                     for (int j = 0; j < deg; ++j) flip(row[j]);
