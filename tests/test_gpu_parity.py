@@ -273,12 +273,15 @@ def test_general_kernel_equals_fused_kernel_bitwise(name):
 
 
 @pytest.mark.parametrize("name,T,kind", [("[[144, 12, 12]]", 12, 1), ("[[288, 12, 18]]", 6, 1),
-                                         ("[[288, 12, 18]]", 7, 2), ("[[288, 12, 18]]", 8, 2)])
+                                         ("[[288, 12, 18]]", 7, 2), ("[[288, 12, 18]]", 8, 2),
+                                         ("[[288, 12, 18]]", 12, 2), ("[[288, 12, 18]]", 18, 2)])
 def test_large_spacetime_matrix_vs_oracle(name, T, kind):
     """Space-time matrices (spaceTime.py:4-18), row weight 8, column weight 3: [[144,12,12]] over 12
     cycles (864 x 2592) and [[288,12,18]] over 6 cycles (864 x 2592, one syndrome per workgroup)
     run on the (8, 4) instantiation of the on-chip kernel; [[288,12,18]] over 7 cycles (m = 1008)
-    needs more than 160 KiB of LDS and over 8 cycles has m = 1152 > 1024: general-H kernel."""
+    needs more than 160 KiB of LDS and over 8 cycles has m = 1152 > 1024: general-H kernel.  Over 12 cycles
+    (1728 x 5184, E = 13 680) the messages fit the LDS only as the ONE in-place array of the undamped
+    sum-product variant; over 18 cycles (2592 x 7776) all but 112 of its slots do."""
     H = codes.load_code(name).Hx
     m, n = H.shape
     Hs = np.kron(np.eye(T, dtype=np.int64), H)
@@ -307,6 +310,13 @@ def test_large_spacetime_matrix_vs_oracle(name, T, kind):
     o = oracle.decode_batch(Hst, syn, prior, 50, threads=8)
     assert np.array_equal(conv, o[1]) and np.array_equal(iters, o[2]) and np.array_equal(hard, o[0])
     assert golden_util.same_bits(llr, o[3]).all()
+    if T >= 12:
+        # the damped variant keeps two message arrays (other memory split of the same matrix): a few syndromes
+        kw = dict(alpha=1.0, damping=0.8, clip_llr=20.0)
+        d = dec.decode(syn[:12], prior, 30, _lib.DAMPED_SP, **kw)
+        od = oracle.decode_batch(Hst, syn[:12], prior, 30, _lib.DAMPED_SP, threads=8, **kw)
+        assert np.array_equal(d[1], od[1]) and np.array_equal(d[2], od[2]) and np.array_equal(d[0], od[0])
+        assert golden_util.same_bits(d[3], od[3]).all()
 
 
 @pytest.mark.parametrize("name,B,variant,kw", [
