@@ -65,3 +65,17 @@ def test_fast_math_flag_is_ignored_by_the_other_kernels():
     assert dec.info("last_kernel") == 2
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     dec.close()
+
+
+def test_fast_math_in_the_monte_carlo_loop():
+    """qbp_mc_run with the flag: same trials (the sampler does not depend on it), and -- decisions being what they
+    are above -- the same classification of all but a handful of marginal trials."""
+    code = codes.load_code("[[72, 12, 6]]")
+    dec = bp.decoder_for(code.Hx)
+    p = 0.05
+    prior = np.full(code.n, np.log((1 - p) / p))
+    a = dec.mc_run(code.Lx, code.distance, p, prior, 0, 40000, seed=4, max_iter=50)
+    b = dec.mc_run(code.Lx, code.distance, p, prior, 0, 40000, seed=4, max_iter=50, flags=_lib.FLAG_FAST_MATH)
+    print(dict(zip(_lib.COUNTER_NAMES, a.tolist())), dict(zip(_lib.COUNTER_NAMES, b.tolist())), sep="\n")
+    assert a[0] == b[0] == 40000
+    assert np.abs(a - b)[:7].max() <= 3 and abs(int(a[7]) - int(b[7])) <= 200      # ([7]: sum of iterations)
