@@ -519,3 +519,24 @@ def test_performOSD_serves_the_driver_loop_from_one_batched_call(monkeypatch):
     assert lb.llr is None                                     # nothing was kept alive
     assert osd._from_last_batch(dec, syn[0].view(np.uint8), np.zeros(n), hard[0].view(np.uint8)) is None
     assert bp._last_batch() is None                           # dead record dropped at the next look
+
+
+def test_python_constants_equal_the_header():
+    """Flags, variants, options and counters of qldpc_amd/_lib.py against the enum values of include/qbp.h
+    (parsed as text: the header is the contract of the ABI)."""
+    import re
+    text = open(os.path.join(ROOT, "include", "qbp.h")).read()
+    enum = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"\b(QBP_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+)u?)", text)}
+    for py, c in (("FLAG_FORCE_FULL", "QBP_FLAG_FORCE_FULL"), ("FLAG_OSD0", "QBP_FLAG_OSD0"),
+                  ("FLAG_PAIRWISE_COLSUM", "QBP_FLAG_PAIRWISE_COLSUM"), ("FLAG_DENSE_F_COLSUM", "QBP_FLAG_DENSE_F_COLSUM"),
+                  ("FLAG_DENSE_F_COLSUM_ITER0", "QBP_FLAG_DENSE_F_COLSUM_ITER0"), ("FLAG_FAST_MATH", "QBP_FLAG_FAST_MATH"),
+                  ("SUM_PRODUCT", "QBP_SUM_PRODUCT"), ("DAMPED_SP", "QBP_DAMPED_SP"), ("MIN_SUM", "QBP_MIN_SUM"),
+                  ("OPT_OSD_BIG", "QBP_OPT_OSD_BIG"), ("OPT_KERNEL", "QBP_OPT_KERNEL"),
+                  ("OPT_FORCE_GENERIC", "QBP_OPT_FORCE_GENERIC"), ("OPT_GENERAL_THREADS", "QBP_OPT_GENERAL_THREADS"),
+                  ("E_UNSUPPORTED", "QBP_E_UNSUPPORTED")):
+        assert getattr(_lib, py) == enum[c], (py, c)
+    flags = [v for k, v in enum.items() if k.startswith("QBP_FLAG_")]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)      # distinct single bits
+    # the drop-in's switch for the approximate arithmetic is off unless asked for
+    from qldpc_amd import bp
+    assert bp.FAST_MATH == (os.environ.get("QBP_FAST_MATH", "0") not in ("0", "")) and (bp._math_flag() != 0) == bp.FAST_MATH
