@@ -23,9 +23,10 @@ sys.path.insert(0, ROOT)
 from qldpc_amd import _lib, bp, codes, mc  # noqa: E402
 
 MAX_ITER = 50
-# (leg name, qbp kernels it launches, in order)
+# (leg name, qbp kernels it launches, in order; osd0_288: the decode, the OSD sweep, its redo pass for inconsistent
+# syndromes)
 ORDER = [("config2_early_exit", 1), ("config2_forced_50", 1), ("config3_early_exit", 1), ("config3_forced_50", 1),
-         ("mc288_p0.01", 1), ("mc288_p0.05", 1), ("mc288_p0.05_osd0", 2), ("osd0_288", 2)]
+         ("mc288_p0.01", 1), ("mc288_p0.05", 1), ("mc288_p0.05_osd0", 2), ("osd0_288", 3)]
 
 
 def _syndromes(dev, code, p, B, seed):
